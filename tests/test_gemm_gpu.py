@@ -1,0 +1,114 @@
+"""GPU parity of the bf16 MFMA GEMM (td_linear_bf16) against an fp32 torch CPU reference.
+
+Tolerance: inputs are bf16-exact on both sides and accumulation is fp32, so the only differences are
+summation order and the final bf16 rounding: |err| <= 2^-8 relative to the row scale (stated per test).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_linear(x, w, b=None, act=0, gate=None, res=None):
+    y = x.float() @ w.float().t()
+    if b is not None:
+        y = y + b.float()
+    y = y.bfloat16().float()
+    if act == 1:
+        y = torch.nn.functional.gelu(y, approximate="tanh").bfloat16().float()
+    elif act == 2:
+        y = torch.nn.functional.gelu(y).bfloat16().float()
+    elif act == 3:
+        y = torch.nn.functional.silu(y).bfloat16().float()
+    if gate is not None:
+        y = (y * gate.float()).bfloat16().float()
+    if res is not None:
+        y = y + res.float()
+    return y.bfloat16()
+
+
+def _close(got, ref, scale_tol=2.0 ** -7):
+    got, ref = got.float().cpu(), ref.float()
+    denom = ref.abs().max().clamp_min(1e-6)
+    err = (got - ref).abs().max() / denom
+    assert torch.isfinite(got).all()
+    assert err < scale_tol, f"max rel-to-scale error {err:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (256, 256, 64), (256, 256, 128), (512, 768, 3072), (193, 3072, 4096), (449, 9216, 3072),
+    (4289, 3072, 3072), (1, 3072, 256), (28, 18432, 3072), (65, 4096, 1408), (4096, 64, 3072),
+    (300, 24, 64), (17, 8, 128),
+])
+def test_linear_plain(hip, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = (torch.randn(M, K, generator=g)).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = (torch.randn(N, generator=g)).bfloat16()
+    y = hip.linear(x.cuda(), w.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(x, w, b))
+
+
+def test_linear_asymmetric_identity(hip):
+    """A = I with an asymmetric W catches a transposed C write (guide 3, 'A=I-check')."""
+    K = 256
+    x = torch.eye(K).bfloat16()
+    w = (torch.arange(K * K).reshape(K, K) % 251).float().bfloat16()  # W[n,k], exact in bf16
+    y = hip.linear(x.cuda(), w.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().float(), w.float().t())
+
+
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_linear_activations(hip, act):
+    g = torch.Generator().manual_seed(act)
+    M, N, K = 300, 512, 256
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.1).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    y = hip.linear(x.cuda(), w.cuda(), b.cuda(), act=act)
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(x, w, b, act=act), 2.0 ** -6)
+
+
+def test_linear_gate_residual_inplace(hip):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 449, 3072, 768
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    gate = torch.randn(N, generator=g).bfloat16()
+    h = torch.randn(M, N, generator=g).bfloat16()
+    hd = h.cuda()
+    hip.linear(x.cuda(), w.cuda(), b.cuda(), gate=gate.cuda(), res=hd, out=hd)
+    torch.cuda.synchronize()
+    _close(hd, _ref_linear(x, w, b, gate=gate, res=h))
+
+
+def test_linear_strided_and_split(hip):
+    """Single-block fused projection: cols [0,n_split) -> qkv, rest -> GELU into a wider buffer."""
+    g = torch.Generator().manual_seed(5)
+    M, K, n_split, n_mlp = 300, 256, 768, 1024
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(n_split + n_mlp, K, generator=g) * 0.1).bfloat16()
+    b = torch.randn(n_split + n_mlp, generator=g).bfloat16()
+    qkv = torch.zeros(M, n_split, dtype=torch.bfloat16, device="cuda")
+    cat = torch.zeros(M, 256 + n_mlp, dtype=torch.bfloat16, device="cuda")
+    hip.linear_split(x.cuda(), w.cuda(), b.cuda(), qkv, 0, cat[:, 256:], 1, n_split)
+    torch.cuda.synchronize()
+    _close(qkv, _ref_linear(x, w[:n_split], b[:n_split]))
+    _close(cat[:, 256:], _ref_linear(x, w[n_split:], b[n_split:], act=1), 2.0 ** -6)
+    assert torch.count_nonzero(cat[:, :256]) == 0
+    # strided A: read the GELU half back as the A operand of a second GEMM
+    w2 = (torch.randn(512, n_mlp, generator=g) * 0.05).bfloat16()
+    y = hip.linear(cat[:, 256:], w2.cuda())
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(cat[:, 256:].cpu(), w2))
+
+
+def test_linear_rejects_bad_k(hip):
+    x = torch.zeros(4, 40, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(8, 40, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(hip.ThinkDiffHipError):
+        hip.linear(x, w)

@@ -1,0 +1,272 @@
+// bf16 "NT" GEMM for gfx950:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )   (fp32 accumulate)
+//
+// This is the one dense-contraction kernel of the FLUX / aligner / Qwen2-VL hot path
+// (SURVEY.md 2.3 rows K1,K2,K4,K5,K6,K8,K12,K13,K14,K15,K19).  Both operands are K-contiguous
+// (torch.nn.Linear weight layout), so the same fragment reader serves both sides.
+//
+// Structure (MI355X_MICROARCH / cdna_hip_programming guide 5):
+//  * 8 waves (2 x 4), block tile BM x BN = (32*WM) x (64*WN), BK = 64, v_mfma_f32_16x16x32_bf16.
+//  * Operand tiles go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB = 8 rows x 128 B
+//    per wave-instruction).  The LDS image is lane-linear, so the bank-conflict XOR swizzle
+//    (16-B chunk ^= row&7) is applied to the per-lane SOURCE address and again on the ds_read.
+//  * The buffer descriptors carry the true extents: rows >= M (or >= N) read as zero, which is
+//    how ragged M (e.g. the 4289-token joint sequence) is handled without padding copies.
+//  * MFMA operand roles are swapped (W fragment = "A" operand) and the W rows are staged in a
+//    permuted order, so that every lane ends with 4*WN CONTIGUOUS output columns of one output
+//    row: the epilogue (bias / activation / gate*x+residual) works on 16-B vectors and the
+//    stores are full 128-B lines per row, with no LDS round trip.
+//  * blockIdx -> tile mapping is XCD-aware (bijective remap + grouped M ordering) so the 32
+//    tiles resident on one XCD share A/W panels through that XCD's L2.
+#include "td_common.h"
+#include "td_kernels.h"
+
+namespace {
+
+constexpr int BK = 64;          // bf16 elements per K tile (= one 128-B LDS row)
+constexpr int ROW_BYTES = 128;  // LDS row pitch
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+  if constexpr (ACT == TD_ACT_GELU_TANH) return gelu_tanh_f(x);
+  else if constexpr (ACT == TD_ACT_GELU_ERF) return gelu_erf_f(x);
+  else if constexpr (ACT == TD_ACT_SILU) return silu_f(x);
+  else return x;
+}
+
+// Lane owns NV = 4*WN contiguous output columns [nbeg, nbeg+NV) of rows mbeg + 16*i.
+// Rounding points follow the reference's bf16 torch pipeline: Linear output, activation,
+// gate multiply and residual add each round to bf16.
+template <int WM, int WN, int ACT>
+__device__ __forceinline__ void epilogue(const TdGemmParams& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second) {
+  constexpr int NV = 4 * WN;
+  bf16_t* Cout = second ? p.C2 : p.C;
+  const int ldo = second ? p.ldc2 : p.ldc;
+  const int ncol = second ? nbeg - p.n_split : nbeg;
+  const bool use_gate = p.gate != nullptr, use_res = p.res != nullptr;
+
+  float bias[NV], gate[NV];
+#pragma unroll
+  for (int c = 0; c < NV; c += 4) {
+    const bool inr = nbeg + c + 4 <= p.N;
+    u32x2_t b = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
+    if (p.bias && inr) b = *(const u32x2_t*)(p.bias + nbeg + c);
+    if (use_gate && inr) g = *(const u32x2_t*)(p.gate + nbeg + c);
+    bias[c] = bf_lo(b[0]); bias[c + 1] = bf_hi(b[0]); bias[c + 2] = bf_lo(b[1]); bias[c + 3] = bf_hi(b[1]);
+    gate[c] = bf_lo(g[0]); gate[c + 1] = bf_hi(g[0]); gate[c + 2] = bf_lo(g[1]); gate[c + 3] = bf_hi(g[1]);
+  }
+
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int m = mbeg + i * 16;
+    const bool mok = m < p.M;
+    float v[NV];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[j][i][r];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      float y = rbf(v[c] + bias[c]);
+      if constexpr (ACT != TD_ACT_NONE) y = rbf(apply_act<ACT>(y));
+      if (use_gate) y = rbf(y * gate[c]);
+      v[c] = y;
+    }
+    if (use_res && mok) {
+      const bf16_t* rp = p.res + (size_t)m * p.ldr + nbeg;
+#pragma unroll
+      for (int c = 0; c < NV; c += 4) {
+        if (nbeg + c + 4 <= p.N) {
+          const u32x2_t rv = *(const u32x2_t*)(rp + c);
+          v[c] += bf_lo(rv[0]); v[c + 1] += bf_hi(rv[0]); v[c + 2] += bf_lo(rv[1]); v[c + 3] += bf_hi(rv[1]);
+        }
+      }
+    }
+    bf16_t* cp = Cout + (size_t)m * ldo + ncol;
+    if constexpr (NV % 8 == 0) {
+#pragma unroll
+      for (int c = 0; c < NV; c += 8) {
+        u32x4_t o;
+        o[0] = pack_bf2(v[c], v[c + 1]); o[1] = pack_bf2(v[c + 2], v[c + 3]);
+        o[2] = pack_bf2(v[c + 4], v[c + 5]); o[3] = pack_bf2(v[c + 6], v[c + 7]);
+        if (mok && nbeg + c + 8 <= p.N) *(u32x4_t*)(cp + c) = o;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NV; c += 4) {
+        u32x2_t o;
+        o[0] = pack_bf2(v[c], v[c + 1]); o[1] = pack_bf2(v[c + 2], v[c + 3]);
+        if (mok && nbeg + c + 4 <= p.N) *(u32x2_t*)(cp + c) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
+  constexpr int BM = 32 * WM, BN = 64 * WN;
+  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int GA = BM / 8, GW = BN / 8;           // 8-row staging groups per tile
+  constexpr int SA = (GA + 7) / 8, SW = (GW + 7) / 8;  // staging instructions per wave
+  constexpr int NV = 4 * WN;                          // contiguous output columns per lane
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  // ---- XCD-aware tile mapping -------------------------------------------------------------
+  int tm, tn;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int gid = t / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsize = min(p.tiles_m - first_m, GROUP_M);
+    const int in_g = t - gid * per_group;
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
+  const unsigned bytesA = (unsigned)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const unsigned bytesW = (unsigned)((long long)p.N * p.K * 2);
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, bytesW, 0x00020000);
+
+  // ---- per-lane staging source offsets ------------------------------------------------------
+  const int srow = lane >> 3;                         // row inside the 8-row group
+  const int schunk = ((lane & 7) ^ srow) << 4;        // swizzled 16-B source chunk
+  unsigned voffA[SA], voffW[SW];
+#pragma unroll
+  for (int s = 0; s < SA; ++s) {
+    const int g = wid + 8 * s;
+    const int row = m0 + g * 8 + srow;
+    voffA[s] = (unsigned)row * (unsigned)p.lda * 2u + schunk;
+  }
+#pragma unroll
+  for (int s = 0; s < SW; ++s) {
+    const int g = wid + 8 * s;
+    const int rho = g * 8 + srow;                     // LDS row of the block's W slab
+    const int wcol = rho / (16 * WN);
+    const int rem = rho - wcol * (16 * WN);
+    const int j = rem >> 4, i16 = rem & 15;
+    const int n = n0 + wcol * (16 * WN) + (i16 >> 2) * NV + j * 4 + (i16 & 3);
+    voffW[s] = (unsigned)n * (unsigned)p.K * 2u + schunk;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE_BYTES;
+    const int soff = kt * (BK * 2);
+#pragma unroll
+    for (int s = 0; s < SA; ++s) {
+      const int g = wid + 8 * s;
+      if (GA % 8 == 0 || g < GA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)(base + g * 1024), 16, voffA[s], soff, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+      const int g = wid + 8 * s;
+      if (GW % 8 == 0 || g < GW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (TD_LDS void*)(base + A_BYTES + g * 1024), 16, voffW[s], soff, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets ------------------------------------------------------------------
+  const int frow = lane & 15;
+  const int foff0 = frow * ROW_BYTES + ((((lane >> 4)) ^ (lane & 7)) << 4);  // k-step 0; k-step 1 = ^64
+  const int aoff = (wr * 16 * WM) * ROW_BYTES;
+  const int woff = A_BYTES + (wc * 16 * WN) * ROW_BYTES;
+
+  f32x4_t acc[WN][WM];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();  // s_waitcnt vmcnt(0) + barrier: tile t landed, buffer (t+1)&1 free
+    if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+    const char* base = smem + (t & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = foff0 ^ (ks << 6);
+      bf16x8_t wf[WN], af[WM];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(base + woff + j * 16 * ROW_BYTES + fo);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8_t*)(base + aoff + i * 16 * ROW_BYTES + fo);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns NV contiguous columns of row (lane&15) of each m-tile -------------
+  const int nbeg = n0 + wc * 16 * WN + (lane >> 4) * NV;
+  if (nbeg >= p.N) return;
+  const bool second = (p.C2 != nullptr) && (n0 >= p.n_split);
+  const int act = second ? p.act2 : p.act;
+  const int mbeg = m0 + wr * 16 * WM + frow;
+  // one instantiation per activation keeps every acc[][] index static (runtime-indexed
+  // accumulators would be demoted to scratch)
+  switch (act) {
+    case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH>(p, acc, mbeg, nbeg, second); break;
+    case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF>(p, acc, mbeg, nbeg, second); break;
+    case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU>(p, acc, mbeg, nbeg, second); break;
+    default: epilogue<WM, WN, TD_ACT_NONE>(p, acc, mbeg, nbeg, second); break;
+  }
+#endif
+}
+
+namespace {
+
+template <int WM, int WN>
+int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
+  constexpr int BM = 32 * WM, BN = 64 * WN;
+  constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
+  TdGemmParams p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int grid = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN>), dim3(grid), dim3(512), LDS, stream, p);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
+  TD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "td_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+  TD_CHECK_ARG(p.K % BK == 0, "td_gemm: K=%d must be a multiple of %d", p.K, BK);
+  TD_CHECK_ARG(p.N % 8 == 0, "td_gemm: N=%d must be a multiple of 8", p.N);
+  TD_CHECK_ARG(p.lda >= p.K && p.ldc >= (p.C2 ? p.n_split : p.N), "td_gemm: bad leading dimensions");
+  TD_CHECK_ARG(((long long)(p.M + 255) * p.lda + p.K) * 2 < (1ll << 32) && (long long)(p.N + 255) * p.K * 2 < (1ll << 32),
+               "td_gemm: operand exceeds the 4 GiB buffer-descriptor range");
+  TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C) % 16 == 0 && p.lda % 8 == 0 && p.ldc % 8 == 0,
+               "td_gemm: pointers / leading dimensions must be 16-byte aligned");
+  if (p.res) TD_CHECK_ARG(p.ldr % 4 == 0, "td_gemm: ldr must be a multiple of 4");
+  if (p.C2) TD_CHECK_ARG(p.ldc2 % 8 == 0 && p.n_split % 8 == 0 && p.n_split < p.N, "td_gemm: bad split-output arguments");
+  if (p.N <= 64) return launch_cfg<8, 1>(p, stream);
+  if (p.M <= 32) return launch_cfg<1, 4>(p, stream);
+  return launch_cfg<8, 4>(p, stream);
+}

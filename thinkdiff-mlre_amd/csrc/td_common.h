@@ -1,0 +1,80 @@
+// Shared device/host helpers for the ThinkDiff gfx950 kernels.
+// Everything here is CDNA4-only (wave64, MFMA, LDS-DMA); there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in HBM
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+#define TD_LDS __attribute__((address_space(3)))
+
+// ---- bf16 <-> f32 -------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+  v2 p;
+  p[0] = (__bf16)lo;
+  p[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, p);
+}
+// round an f32 through bf16 (emulates one torch bf16 op boundary of the reference pipeline)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// ---- activations (fp32 math) -------------------------------------------
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float e = __expf(2.0f * u);
+  const float t = 1.0f - 2.0f / (e + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- wave reductions (wave64) ------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- error plumbing shared by the C-ABI translation units ---------------
+void td_set_error(const char* fmt, ...);
+#define TD_CHECK_ARG(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      td_set_error(__VA_ARGS__);         \
+      return 2; /* TD_ERR_INVALID */     \
+    }                                    \
+  } while (0)
+#define TD_CHECK_HIP(expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      td_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 3; /* TD_ERR_HIP */                                                  \
+    }                                                                             \
+  } while (0)
+#define TD_CHECK_LAUNCH() TD_CHECK_HIP(hipGetLastError())

@@ -1,0 +1,23 @@
+// Internal launch interface between the kernel translation units and the C-ABI / engine.
+// Not installed; the public surface is include/thinkdiff_hip.h.
+#pragma once
+#include "td_common.h"
+
+enum TdAct { TD_ACT_NONE = 0, TD_ACT_GELU_TANH = 1, TD_ACT_GELU_ERF = 2, TD_ACT_SILU = 3 };
+
+struct TdGemmParams {
+  const bf16_t* A = nullptr;     // [M, lda]  activations, K-contiguous
+  const bf16_t* W = nullptr;     // [N, K]    torch Linear weight layout
+  const bf16_t* bias = nullptr;  // [N] or null
+  bf16_t* C = nullptr;           // [M, ldc]
+  const bf16_t* gate = nullptr;  // [N] or null : y *= gate[n]
+  const bf16_t* res = nullptr;   // [M, ldr] or null : y += res[m,n]   (may alias C)
+  bf16_t* C2 = nullptr;          // optional second output for columns >= n_split
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldc = 0, ldr = 0, ldc2 = 0;
+  int n_split = 0;
+  int act = TD_ACT_NONE, act2 = TD_ACT_NONE;
+  int tiles_m = 0, tiles_n = 0;  // filled by the launcher
+};
+
+int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);

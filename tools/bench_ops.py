@@ -1,0 +1,48 @@
+"""Micro-benchmarks of the individual HIP ops on the GPU box (not the headline bench)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "thinkdiff-mlre_amd"))
+from thinkdiff import _hip  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def bench_gemm():
+    shapes = [  # (M, N, K) of the FLUX.1-dev cfg-2 step
+        (4096, 9216, 3072), (4096, 3072, 3072), (4096, 12288, 3072), (4096, 3072, 12288),
+        (4289, 21504, 3072), (4289, 3072, 15360), (193, 9216, 3072), (193, 12288, 3072),
+        (4096, 4096, 4096), (8192, 8192, 8192), (28, 18432, 3072),
+    ]
+    for M, N, K in shapes:
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+        b = torch.randn(N, device="cuda").bfloat16()
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ms = timeit(lambda: _hip.linear(x, w, b, out=out))
+        tf = 2.0 * M * N * K / ms / 1e9
+        ref_ms = timeit(lambda: torch.nn.functional.linear(x, w, b))
+        print(f"gemm M={M:5d} N={N:5d} K={K:5d}: {ms:8.3f} ms  {tf:7.1f} TF/s   (hipBLASLt via torch: {ref_ms:8.3f} ms {2.0*M*N*K/ref_ms/1e9:7.1f} TF/s)", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["gemm"])
+    a = ap.parse_args()
+    for w in a.what:
+        globals()["bench_" + w]()
