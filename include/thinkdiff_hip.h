@@ -45,6 +45,18 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
                          void* y0, int64_t ldy0, int act0, void* y1, int64_t ldy1, int act1,
                          int M, int N, int K, int n_split, void* stream);
 
+/* o[b,s,h*128+d] = softmax(q.k^T * scale (+causal mask)) . v, head_dim 128, fp32 softmax state.
+ * q/k/v/o are token-major: row s of batch b at  ptr + b*bstride + s*ld  (elements), head h at
+ * column h*128, so the fused QKV projection output is consumed in place.  Hq % Hkv == 0 (GQA).
+ * causal != 0: key j visible to query i iff j <= i + (Skv - Sq).
+ * Replaces F.scaled_dot_product_attention in [ext] diffusers 0.31.0 attention_processor.py
+ * FluxAttnProcessor2_0 / FluxSingleAttnProcessor2_0 (joint [text||image] attention, no mask) and
+ * the vLLM fork's Qwen2-VL attention (thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:1083). */
+int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void* k, const void* v,
+                      int64_t ldkv, int64_t kv_bstride, void* o, int64_t ldo, int64_t o_bstride,
+                      int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,
+                      int causal, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,91 @@
+"""GPU parity of the fused attention kernel (td_attention_bf16) vs fp32 torch CPU softmax(QK^T)V.
+
+Tolerance: P is rounded to bf16 before the PV product (as in flash-style kernels the reference's
+SDPA dispatches to) and the output is bf16: |err| <= 2^-7 of the output scale.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, Hq, Hkv, causal):
+    B, Sq, _ = q.shape
+    Skv = k.shape[1]
+    qh = q.float().reshape(B, Sq, Hq, 128).transpose(1, 2)
+    kh = k.float().reshape(B, Skv, Hkv, 128).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    vh = v.float().reshape(B, Skv, Hkv, 128).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(128)
+    if causal:
+        i = torch.arange(Sq)[:, None] + (Skv - Sq)
+        j = torch.arange(Skv)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    o = torch.softmax(s, dim=-1) @ vh
+    return o.transpose(1, 2).reshape(B, Sq, Hq * 128)
+
+
+def _check(got, ref, tol=2.0 ** -7):
+    got = got.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < tol, f"rel-to-scale err {err:.3e}"
+
+
+@pytest.mark.parametrize("S,H", [(64, 1), (256, 2), (449, 4), (1000, 3), (4289, 2)])
+def test_joint_attention_inplace_qkv(hip, S, H):
+    """FLUX layout: one [S, 3*H*128] projection buffer, q|k|v column blocks, output [S, H*128]."""
+    g = torch.Generator().manual_seed(S + H)
+    qkv = torch.randn(1, S, 3 * H * 128, generator=g).bfloat16()
+    d = qkv.cuda()
+    q, k, v = d[:, :, :H * 128], d[:, :, H * 128:2 * H * 128], d[:, :, 2 * H * 128:]
+    out = torch.zeros(1, S, H * 128, dtype=torch.bfloat16, device="cuda")
+    hip.attention(q, k, v, out, H, H)
+    torch.cuda.synchronize()
+    c = qkv
+    _check(out, _ref(c[:, :, :H * 128], c[:, :, H * 128:2 * H * 128], c[:, :, 2 * H * 128:], H, H, False))
+
+
+def test_attention_peaked_rows(hip):
+    """Forces the online-softmax rescale: one key per row dominates late in the sequence."""
+    g = torch.Generator().manual_seed(3)
+    S, H = 512, 1
+    q = torch.randn(1, S, 128, generator=g)
+    k = torch.randn(1, S, 128, generator=g)
+    v = torch.randn(1, S, 128, generator=g)
+    k[0, 400] = q[0, 7] * 4.0      # row 7 spikes at key 400 (tile 6)
+    k[0, 130] = q[0, 300] * 3.0    # row 300 spikes at key 130
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    out = torch.zeros(1, S, 128, dtype=torch.bfloat16, device="cuda")
+    hip.attention(q.cuda(), k.cuda(), v.cuda(), out, 1, 1)
+    torch.cuda.synchronize()
+    _check(out, _ref(q, k, v, 1, 1, False))
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,B", [(300, 4, 2, 2), (1029, 28, 4, 1), (64, 2, 1, 1)])
+def test_causal_gqa(hip, S, Hq, Hkv, B):
+    """Qwen2-VL layout: fused [q(Hq)|k(Hkv)|v(Hkv)] projection, causal, grouped-query."""
+    g = torch.Generator().manual_seed(S)
+    W = (Hq + 2 * Hkv) * 128
+    qkv = torch.randn(B, S, W, generator=g).bfloat16()
+    d = qkv.cuda()
+    sl = lambda t: (t[:, :, :Hq * 128], t[:, :, Hq * 128:(Hq + Hkv) * 128], t[:, :, (Hq + Hkv) * 128:])
+    q, k, v = sl(d)
+    out = torch.zeros(B, S, Hq * 128, dtype=torch.bfloat16, device="cuda")
+    hip.attention(q, k, v, out, Hq, Hkv, causal=True)
+    torch.cuda.synchronize()
+    _check(out, _ref(*sl(qkv), Hq, Hkv, True))
+
+
+def test_attention_strided_output(hip):
+    """Single-block layout: attention output lands in columns [0, H*128) of the wider cat buffer."""
+    g = torch.Generator().manual_seed(9)
+    S, H = 300, 2
+    qkv = torch.randn(1, S, 3 * H * 128, generator=g).bfloat16()
+    d = qkv.cuda()
+    cat = torch.zeros(1, S, H * 128 + 512, dtype=torch.bfloat16, device="cuda")
+    hip.attention(d[:, :, :256], d[:, :, 256:512], d[:, :, 512:], cat[:, :, :H * 128], H, H)
+    torch.cuda.synchronize()
+    _check(cat[:, :, :H * 128], _ref(qkv[:, :, :256], qkv[:, :, 256:512], qkv[:, :, 512:], H, H, False))
+    assert torch.count_nonzero(cat[:, :, H * 128:]) == 0

@@ -1,0 +1,280 @@
+// Flash-style fused attention forward for gfx950, head_dim = 128, bf16 in/out, fp32 softmax state.
+//
+// Serves K11: FLUX joint attention over [text || image] tokens (non-causal, no
+// mask, 24 heads, S ~ 4.3k) and K19: Qwen2-VL prefill attention (causal, GQA 28q/4kv).
+// Replaces F.scaled_dot_product_attention inside [ext] diffusers FluxAttnProcessor2_0 /
+// FluxSingleAttnProcessor2_0 and the vLLM fork's Qwen2-VL attention.
+//
+// Structure (cdna_hip_programming guide, Appendix B "Fused attention prefill"):
+//  * workgroup = 8 waves, each wave owns 32 query rows (256 rows / workgroup); KV tile = 64 keys.
+//  * swapped QK^T: S^T[key][q] = K . Q^T on v_mfma_f32_32x32x16_bf16, so one query row lives on
+//    one lane (and its lane+32 partner): the online softmax is in-register, the row max / row sum
+//    need one half-swap (v_permlane32_swap) and no LDS.
+//  * the S^T accumulator, converted to bf16 in place, IS the B operand of the P.V product
+//    (O^T[d][q] += V^T[d][key] . P^T[key][q]); V^T fragments come from a row-major V tile through
+//    ds_read_b64_tr_b16 (hardware transpose read).
+//  * K/V tiles travel HBM -> LDS by LDS-DMA (buffer_load ... lds), double buffered; both tiles use
+//    the one 256-B-row XOR image that is conflict-free for row reads and transposed reads
+//    (off(row,ch) = 256 row + 16 (ch ^ ((row&3)<<2 | (row>>2)&3))), applied on the DMA source side.
+//  * q/k/v are read in place from the projection output ([S, ld] rows, head h at column h*128):
+//    no head-major re-layout pass exists anywhere on the path.
+#include "td_common.h"
+#include "td_kernels.h"
+
+namespace {
+
+constexpr int D = 128;          // head dim
+constexpr int KV_TILE = 64;     // keys per iteration
+constexpr int Q_WAVE = 32;      // query rows per wave
+constexpr int TILE_BYTES = KV_TILE * D * 2;  // 16 KiB per K or V tile
+
+// v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b.  Starting from a == b == x this
+// leaves a = {x.lo, x.lo}, b = {x.hi, x.hi}: every lane then sees both halves of its row.
+// (Inline asm on two distinct registers: hipcc folds the builtin called with identical operands.)
+__device__ __forceinline__ void half_swap(float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float half_swap_max(float x) {
+  float a, b;
+  half_swap(x, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+  float a, b;
+  half_swap(x, a, b);
+  return a + b;
+}
+
+}  // namespace
+
+template <bool CAUSAL, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const TdAttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5;       // lane half
+  const int l31 = lane & 31;
+
+  const int qblk = blockIdx.x;
+  const int head = blockIdx.y;
+  const int batch = blockIdx.z;
+  const int kvhead = head / p.q_per_kv;
+  const int q0 = qblk * (NWAVES * Q_WAVE) + wid * Q_WAVE;  // first query row of this wave
+
+  const bf16_t* Qb = p.Q + (size_t)batch * p.q_bstride;
+  const bf16_t* Kb = p.K + (size_t)batch * p.kv_bstride;
+  const bf16_t* Vb = p.V + (size_t)batch * p.kv_bstride;
+  bf16_t* Ob = p.O + (size_t)batch * p.o_bstride;
+
+  const unsigned q_bytes = (unsigned)(((long long)(p.Sq - 1) * p.ldq + p.Hq * D) * 2);
+  const unsigned kv_bytes = (unsigned)(((long long)(p.Skv - 1) * p.ldkv + p.Hkv * D) * 2);
+  __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, q_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, kv_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, kv_bytes, 0x00020000);
+
+  // ---- number of KV tiles this workgroup visits ----------------------------------------------
+  int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
+  if (CAUSAL) {
+    const int last_q = min(p.Sq, (qblk + 1) * NWAVES * Q_WAVE) - 1 + p.causal_offset;
+    nt = min(nt, last_q / KV_TILE + 1);
+  }
+
+  // ---- staging (LDS-DMA): 16 groups of 4 rows per tile, NWAVES waves share them ---------------
+  constexpr int GROUPS = KV_TILE / 4;
+  constexpr int SG = (GROUPS + NWAVES - 1) / NWAVES;
+  const int srow = lane >> 4;  // row inside the 4-row group
+  unsigned voffK[SG];
+#pragma unroll
+  for (int s = 0; s < SG; ++s) {
+    const int g = wid + NWAVES * s;
+    const int swz = (srow << 2) | (g & 3);
+    const int chunk = (lane & 15) ^ swz;
+    voffK[s] = (unsigned)(g * 4 + srow) * (unsigned)p.ldkv * 2u + (unsigned)(kvhead * D + chunk * 8) * 2u;
+  }
+  auto stage = [&](int buf, int t) {
+    char* base = smem + buf * (2 * TILE_BYTES);
+    const unsigned tile_off = (unsigned)t * KV_TILE * (unsigned)p.ldkv * 2u;
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
+      const int g = wid + NWAVES * s;
+      if (GROUPS % NWAVES == 0 || g < GROUPS) {
+        // row part stays in voffset so the descriptor range check sees it: keys >= Skv read as 0
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(base + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(base + TILE_BYTES + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+      }
+    }
+  };
+
+  stage(0, 0);
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + l31][16 ks + 8 h5 .. +8] -----
+  bf16x8_t qf[8];
+  {
+    const unsigned qoff = (unsigned)(q0 + l31) * (unsigned)p.ldq * 2u + (unsigned)(head * D + 8 * h5) * 2u;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + ks * 32, 0, 0);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  // ---- per-lane LDS read offsets ----------------------------------------------------------------
+  // K row read: row = kb*32 + l31, chunk = 2 ks + h5
+  const int ksw = ((lane & 3) << 2) | ((lane >> 2) & 3);
+  const int krow_off = l31 * 256;
+  // V transposed read: lane i=lane&15 of its 16-lane group addresses row q=i>>2, cols 4p..4p+3 (p=i&3)
+  const int vq = (lane & 15) >> 2, vp = lane & 3;
+  const int vrow_base = 4 * h5 + vq;                 // + kb*32 + 16 s + 8 jj
+  const int vchunk_base = 2 * ((lane >> 4) & 1) + (vp >> 1);  // + 4 db
+
+  f32x16_t o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -1e30f;   // running row max (raw score units)
+  float l_run = 0.f;      // this lane-half's partial row sum
+  const float c = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c)
+  const int q_pos = q0 + l31 + p.causal_offset;   // causal: keys <= q_pos visible
+
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();  // vmcnt(0) + barrier: tile t landed; buffer (t+1)&1 no longer read
+    if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+    const char* kbuf = smem + (t & 1) * (2 * TILE_BYTES);
+    const char* vbuf = kbuf + TILE_BYTES;
+
+    // ---- S^T = K . Q^T ------------------------------------------------------------------------
+    f32x16_t st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(kbuf + kb * 32 * 256 + krow_off + (((2 * ks + h5) ^ ksw) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- masking: tail keys (>= Skv) and causal --------------------------------------------------
+    const int key0 = t * KV_TILE;
+    const bool need_mask = (key0 + KV_TILE > p.Skv) || (CAUSAL && key0 + KV_TILE - 1 > q0 + p.causal_offset);
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+          const bool dead = (key >= p.Skv) || (CAUSAL && key > q_pos);
+          if (dead) st[kb][r] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (row = query = lane & 31, split over the two lane halves) -------------
+    float mx = st[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = half_swap_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+    const float mc = m_new * c;
+    float psum = 0.f;
+    bf16x8_t pf[2][2];  // [kb][s] B-operand fragments of P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4_t pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s + 2 * j] * c - mc);
+          const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s + 2 * j + 1] * c - mc);
+          psum += p0 + p1;
+          pk[j] = pack_bf2(p0, p1);
+        }
+        pf[kb][s] = __builtin_bit_cast(bf16x8_t, pk);
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ------------------------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          bf16x4_t v01[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int row = kb * 32 + 16 * s + 8 * jj + vrow_base;
+            const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+            const int off = row * 256 + (((4 * db + vchunk_base) ^ swz) << 4) + 8 * (vp & 1);
+            v01[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(vbuf + off));
+          }
+          bf16x8_t vf;
+          vf[0] = v01[0][0]; vf[1] = v01[0][1]; vf[2] = v01[0][2]; vf[3] = v01[0][3];
+          vf[4] = v01[1][0]; vf[5] = v01[1][1]; vf[6] = v01[1][2]; vf[7] = v01[1][3];
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], o[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] --------------------
+  const float l_tot = half_swap_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.Sq) {
+    bf16_t* op = Ob + (size_t)q * p.ldo + head * D + 4 * h5;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        *(u32x2_t*)(op + db * 32 + 8 * g) = w;
+      }
+  }
+#endif
+}
+
+int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
+  TD_CHECK_ARG(p.head_dim == D, "td_attention: head_dim=%d unsupported (only 128)", p.head_dim);
+  TD_CHECK_ARG(p.Sq > 0 && p.Skv > 0 && p.Hq > 0 && p.Hkv > 0 && p.batch > 0, "td_attention: empty problem");
+  TD_CHECK_ARG(p.Hq % p.Hkv == 0, "td_attention: Hq=%d not a multiple of Hkv=%d", p.Hq, p.Hkv);
+  TD_CHECK_ARG(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "td_attention: row strides must be 16-byte multiples");
+  TD_CHECK_ARG(((long long)(p.Sq + 256) * p.ldq) * 2 < (1ll << 32) && ((long long)(p.Skv + 64) * p.ldkv) * 2 < (1ll << 32),
+               "td_attention: per-batch operand exceeds the 4 GiB buffer-descriptor range");
+  TD_CHECK_ARG(((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0, "td_attention: pointers must be 16-byte aligned");
+  constexpr int NW = 8;
+  constexpr int LDS = 4 * TILE_BYTES;  // 2 buffers x (K + V)
+  TdAttnParams q = p;
+  q.q_per_kv = p.Hq / p.Hkv;
+  dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  if (p.causal)
+    hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW>), grid, dim3(NW * 64), LDS, stream, q);
+  else
+    hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW>), grid, dim3(NW * 64), LDS, stream, q);
+  TD_CHECK_LAUNCH();
+  return 0;
+}

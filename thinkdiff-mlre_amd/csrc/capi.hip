@@ -42,4 +42,17 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
   return td_gemm_launch(p, (hipStream_t)stream);
 }
 
+int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void* k, const void* v,
+                      int64_t ldkv, int64_t kv_bstride, void* o, int64_t ldo, int64_t o_bstride,
+                      int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,
+                      int causal, void* stream) {
+  TdAttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o;
+  p.batch = batch; p.Sq = Sq; p.Skv = Skv; p.Hq = Hq; p.Hkv = Hkv; p.head_dim = head_dim;
+  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo;
+  p.q_bstride = q_bstride; p.kv_bstride = kv_bstride; p.o_bstride = o_bstride;
+  p.scale = scale; p.causal = causal; p.causal_offset = Skv - Sq;
+  return td_attn_launch(p, (hipStream_t)stream);
+}
+
 }  // extern "C"

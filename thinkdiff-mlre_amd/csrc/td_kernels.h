@@ -21,3 +21,19 @@ struct TdGemmParams {
 };
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);
+
+// q/k/v are read in place from projection outputs: token row s, head h at column h*128.
+struct TdAttnParams {
+  const bf16_t* Q = nullptr;  // [batch][Sq, ldq]
+  const bf16_t* K = nullptr;  // [batch][Skv, ldkv]
+  const bf16_t* V = nullptr;  // [batch][Skv, ldkv]
+  bf16_t* O = nullptr;        // [batch][Sq, ldo]
+  int batch = 1, Sq = 0, Skv = 0, Hq = 0, Hkv = 0, head_dim = 128;
+  int ldq = 0, ldkv = 0, ldo = 0;
+  long long q_bstride = 0, kv_bstride = 0, o_bstride = 0;  // elements
+  float scale = 0.f;
+  int causal = 0, causal_offset = 0;  // key visible iff key <= q + causal_offset
+  int q_per_kv = 1;                   // filled by the launcher
+};
+
+int td_attn_launch(const TdAttnParams& p, hipStream_t stream);

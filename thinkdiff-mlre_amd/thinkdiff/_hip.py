@@ -41,6 +41,7 @@ def _declare(L):
         "td_abi_version": [],
         "td_linear_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp],
         "td_linear_split_bf16": [vp, i64, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp],
+        "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -89,3 +90,19 @@ def linear_split(x, w, bias, out0, act0, out1, act1, n_split):
     check(lib().td_linear_split_bf16(ptr(x), _rows(x), ptr(w), ptr(bias), ptr(out0), _rows(out0), act0,
                                      ptr(out1), _rows(out1), act1, M, N, K, n_split, stream_ptr()))
     return out0, out1
+
+
+def attention(q, k, v, out, Hq, Hkv, scale=None, causal=False):
+    """q:[B,Sq,>=Hq*128] k,v:[B,Skv,>=Hkv*128] (views into projection outputs) -> out:[B,Sq,>=Hq*128]."""
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3 and out.dim() == 3
+    B, Sq, _ = q.shape
+    Skv = k.shape[1]
+    for t in (q, k, v, out):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1
+    assert k.stride() == v.stride()
+    if scale is None:
+        scale = 128 ** -0.5
+    check(lib().td_attention_bf16(ptr(q), q.stride(1), q.stride(0), ptr(k), ptr(v), k.stride(1), k.stride(0),
+                                  ptr(out), out.stride(1), out.stride(0), B, Sq, Skv, Hq, Hkv, 128,
+                                  float(scale), int(causal), stream_ptr()))
+    return out

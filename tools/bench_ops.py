@@ -40,6 +40,20 @@ def bench_gemm():
         print(f"gemm M={M:5d} N={N:5d} K={K:5d}: {ms:8.3f} ms  {tf:7.1f} TF/s   (hipBLASLt via torch: {ref_ms:8.3f} ms {2.0*M*N*K/ref_ms/1e9:7.1f} TF/s)", flush=True)
 
 
+def bench_attn():
+    for S, H in [(4289, 24), (4224, 24), (4096, 24), (8192, 24)]:
+        qkv = torch.randn(1, S, 3 * H * 128, device="cuda").bfloat16()
+        out = torch.empty(1, S, H * 128, device="cuda", dtype=torch.bfloat16)
+        q, k, v = qkv[:, :, :H * 128], qkv[:, :, H * 128:2 * H * 128], qkv[:, :, 2 * H * 128:]
+        ms = timeit(lambda: _hip.attention(q, k, v, out, H, H))
+        fl = 4.0 * S * S * H * 128
+        qh = q.reshape(1, S, H, 128).transpose(1, 2)
+        kh = k.reshape(1, S, H, 128).transpose(1, 2)
+        vh = v.reshape(1, S, H, 128).transpose(1, 2)
+        ref_ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh))
+        print(f"attn S={S} H={H}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s   (torch SDPA: {ref_ms:8.3f} ms {fl/ref_ms/1e9:7.1f} TF/s)", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["gemm"])
