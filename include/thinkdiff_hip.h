@@ -57,6 +57,79 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
                       int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,
                       int causal, void* stream);
 
+/* ---- row kernels (each is also used inside the FLUX engine) -------------------------------------- */
+
+/* y = norm(x) [* w] [modulated]:  rms=0 LayerNorm(no affine, eps) as in [ext] diffusers
+ * AdaLayerNormZero/Single/Continuous, rms=1 RMSNorm as T5LayerNorm (aligner tail,
+ * thinkdiff/models/blip_vision_t5_decoder.py:50-53) and Qwen2RMSNorm.  Optional adaLN modulation
+ * y = y*(1+scale)+shift with separate (shift,scale) for rows < split and rows >= split. D % 512 == 0. */
+int td_norm_rows_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, int rms, float eps,
+                      const void* w, int split, const void* shiftA, const void* scaleA,
+                      const void* shiftB, const void* scaleB, void* stream);
+
+/* In-place per-head RMSNorm(q), RMSNorm(k) (weights may be NULL = no norm) + rotary embedding on a
+ * fused projection buffer.  rotate_half=0: FLUX interleaved pairs ([ext] diffusers apply_rotary_emb);
+ * rotate_half=1: Qwen2 half-split.  cos/sin: fp32 [rows,128]. */
+int td_qk_norm_rope_bf16(void* qkv, int64_t ld, int rows, int Hq, int Hk, int q_col, int k_col,
+                         const float* cos, const float* sin, int split, const void* wqA, const void* wkA,
+                         const void* wqB, const void* wkB, float eps, int rotate_half, void* stream);
+
+/* FluxPosEmbed tables: ids fp32 [S,3] -> cos,sin fp32 [S,128]. */
+int td_flux_rope_table(const float* ids, int S, const int* axes_dims3, double theta, float* cos, float* sin, void* stream);
+/* Timesteps(256) sinusoid: t fp32 [n] (device) -> bf16 [n,256] = [cos | sin]. */
+int td_timestep_sincos(const float* t, int n, void* out, void* stream);
+/* FlowMatchEulerDiscreteScheduler.step on bf16 latents: x = bf16(float(x) + dt*float(v)). */
+int td_euler_step_bf16(void* x, const void* v, float dt, int64_t n, void* stream);
+/* FluxPipeline._pack_latents (unpack=0: [C,H,W] -> [(H/2)(W/2),4C]) / _unpack_latents (unpack=1, with
+ * out = in*mul + add, i.e. the z/scaling_factor + shift_factor that precedes vae.decode). */
+int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float mul, float add, void* stream);
+/* ThinkDiff-CLIP token pooling (blip_vision_t5_decoder.py:620-637): [1+G*G,C] -> [1+(G/2)^2,C]. */
+int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream);
+/* counter-based N(mean,std) fill (synthetic checkpoints for throughput runs). */
+int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float mean, void* stream);
+
+/* ---- FLUX.1 MMDiT denoise engine ------------------------------------------------------------------
+ * Replaces the `diffusion_pipe(prompt_embeds=..., pooled_prompt_embeds=..., height, width,
+ * num_inference_steps, guidance_scale)` denoise loop the reference drivers call
+ * (scripts/test/test_blip_vision_t5_decoder_flux_text.py:234-242, scripts/test/
+ * test_mllama_t5_decoder_flux.py:182-192), i.e. [ext] diffusers 0.31.0 FluxTransformer2DModel.forward
+ * + FlowMatchEulerDiscreteScheduler.step.  Parameters are addressed by their diffusers state-dict
+ * names (e.g. "transformer_blocks.3.attn.to_k.weight"), so a FLUX.1-dev checkpoint loads unchanged. */
+typedef struct td_flux td_flux;
+typedef struct TdFluxConfig {
+  int in_channels;        /* 64  */
+  int num_layers;         /* 19  */
+  int num_single_layers;  /* 38  */
+  int num_heads;          /* 24  */
+  int head_dim;           /* 128 */
+  int joint_dim;          /* 4096 */
+  int pooled_dim;         /* 768 */
+  int guidance_embeds;    /* 1   */
+  int mlp_ratio;          /* 4   */
+  int axes_dims[3];       /* 16,56,56 */
+  float rope_theta;       /* 10000 */
+} TdFluxConfig;
+
+int td_flux_create(const TdFluxConfig* cfg, int max_img_tokens, int max_txt_tokens, int max_steps, td_flux** out);
+void td_flux_destroy(td_flux* f);
+int64_t td_flux_param_elems(const td_flux* f);
+int td_flux_num_params(const td_flux* f);
+int td_flux_param_info(const td_flux* f, int idx, char* name_buf, int buf_len, int64_t* count);
+/* copy one parameter (device bf16, `count` elements) into the engine's fused weight arena */
+int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t count, void* stream);
+int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream);
+/* per prompt: prompt_embeds bf16 [T,joint_dim], pooled bf16 [pooled_dim], ids fp32 device [n,3]
+ * (txt_ids NULL = zeros, thinkdiff/models/flux_prompt.py:119) */
+int td_flux_set_condition(td_flux* f, const void* prompt_embeds, int T, const void* pooled, const float* txt_ids,
+                          const float* img_ids, int S_img, void* stream);
+/* per schedule: t_eff (host, n floats) / g_eff = the values fed to the sinusoids (timestep*1000,
+ * guidance*1000 after the pipeline's dtype casts); precomputes temb and every adaLN modulation */
+int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, void* stream);
+/* velocity[S_img,in_channels] = transformer(latents[S_img,in_channels]; prepared step) */
+int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, void* stream);
+/* n Euler steps in place; sigmas: n+1 host floats */
+int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

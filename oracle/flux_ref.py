@@ -1,0 +1,332 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of the FLUX.1 MMDiT denoise path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+**Parity unpinned.**  The reference (avi22bhattacharya/ThinkDiff-mlre) runs this stage inside the
+third-party package `diffusers==0.31.0` (reference requirements.txt:34), which is neither vendored
+under /root/reference nor installed here, and the reference ships no tests or golden vectors for it
+(SURVEY.md 4, 8c).  This file restates the published diffusers 0.31.0 algorithm, anchored on the
+reference's own call sites:
+  scripts/test/test_blip_vision_t5_decoder_flux_text.py:234-242  (diffusion_pipe(prompt_embeds=..., 1024^2, 28 steps, g=3.5))
+  thinkdiff/models/flux_prompt.py:37-121                        (encode_prompt: text_ids = zeros[T,3])
+Every function names the diffusers 0.31.0 source it follows ([ext] = not in /root/reference).
+
+`dtype=torch.bfloat16` runs the same torch ops the reference runs (bf16 storage, each op rounding
+to bf16, fp32 inside LayerNorm / RoPE / scheduler) -- this is "the reference's CPU path";
+`dtype=torch.float32` is the exact-arithmetic version of the same graph.
+"""
+from dataclasses import dataclass, field
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class FluxConfig:
+    """[ext] FLUX.1-dev transformer/config.json."""
+    in_channels: int = 64
+    num_layers: int = 19
+    num_single_layers: int = 38
+    attention_head_dim: int = 128
+    num_attention_heads: int = 24
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 768
+    guidance_embeds: bool = True
+    axes_dims_rope: Tuple[int, int, int] = (16, 56, 56)
+    mlp_ratio: int = 4
+
+    @property
+    def inner_dim(self):
+        return self.attention_head_dim * self.num_attention_heads
+
+
+def tiny_config(**kw):
+    base = dict(in_channels=64, num_layers=2, num_single_layers=3, num_attention_heads=4,
+                joint_attention_dim=512, pooled_projection_dim=256)
+    base.update(kw)
+    return FluxConfig(**base)
+
+
+# ----------------------------------------------------------------------------------------------
+# parameters (diffusers state-dict names)
+# ----------------------------------------------------------------------------------------------
+def param_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
+    D, hd = cfg.inner_dim, cfg.attention_head_dim
+    M = cfg.mlp_ratio * D
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(name, out_f, in_f):
+        s[name + ".weight"] = (out_f, in_f)
+        s[name + ".bias"] = (out_f,)
+
+    lin("x_embedder", D, cfg.in_channels)
+    lin("context_embedder", D, cfg.joint_attention_dim)
+    lin("time_text_embed.timestep_embedder.linear_1", D, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", D, D)
+    if cfg.guidance_embeds:
+        lin("time_text_embed.guidance_embedder.linear_1", D, 256)
+        lin("time_text_embed.guidance_embedder.linear_2", D, D)
+    lin("time_text_embed.text_embedder.linear_1", D, cfg.pooled_projection_dim)
+    lin("time_text_embed.text_embedder.linear_2", D, D)
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}."
+        lin(p + "norm1.linear", 6 * D, D)
+        lin(p + "norm1_context.linear", 6 * D, D)
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            lin(p + "attn." + n, D, D)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            s[p + f"attn.{n}.weight"] = (hd,)
+        lin(p + "ff.net.0.proj", M, D)
+        lin(p + "ff.net.2", D, M)
+        lin(p + "ff_context.net.0.proj", M, D)
+        lin(p + "ff_context.net.2", D, M)
+    for i in range(cfg.num_single_layers):
+        p = f"single_transformer_blocks.{i}."
+        lin(p + "norm.linear", 3 * D, D)
+        lin(p + "proj_mlp", M, D)
+        lin(p + "proj_out", D, D + M)
+        for n in ("to_q", "to_k", "to_v"):
+            lin(p + "attn." + n, D, D)
+        for n in ("norm_q", "norm_k"):
+            s[p + f"attn.{n}.weight"] = (hd,)
+    lin("norm_out.linear", 2 * D, D)
+    lin("proj_out", cfg.in_channels, D)
+    return s
+
+
+def init_weights(cfg: FluxConfig, seed: int = 0, std: float = 0.02, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic checkpoint: W ~ N(0,std), b ~ N(0,std), RMSNorm weights ~ 1 + N(0,0.1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in param_shapes(cfg).items():
+        if ".norm_" in name and name.endswith(".weight") and len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = std * torch.randn(shape, generator=g)
+        sd[name] = t.to(dtype)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# embeddings
+# ----------------------------------------------------------------------------------------------
+def timestep_proj(t: torch.Tensor) -> torch.Tensor:
+    """[ext] embeddings.get_timestep_embedding(256, flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    half = 128
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.0):
+    """[ext] embeddings.FluxPosEmbed.forward: fp64 freqs, cos/sin repeat_interleave(2) -> fp32 [S,128]."""
+    pos = ids.double()
+    cos_out, sin_out = [], []
+    for i, d in enumerate(axes_dims):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+        ang = torch.outer(pos[:, i], freqs)
+        cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+        sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos_out, dim=-1), torch.cat(sin_out, dim=-1)
+
+
+def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """[ext] embeddings.apply_rotary_emb(use_real=True, use_real_unbind_dim=-1). x: [B,H,S,hd]."""
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * cos[None, None] + x_rot.float() * sin[None, None]).to(x.dtype)
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """[ext] normalization.RMSNorm.forward (fp32 variance, cast to weight dtype, times weight)."""
+    var = x.float().pow(2).mean(-1, keepdim=True)
+    y = x * torch.rsqrt(var + eps)
+    if w.dtype in (torch.float16, torch.bfloat16):
+        y = y.to(w.dtype)
+    return y * w
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _ln(x):
+    return F.layer_norm(x, (x.shape[-1],), eps=1e-6)
+
+
+def time_text_embed(sd, cfg, timestep, guidance, pooled):
+    """[ext] embeddings.CombinedTimestepGuidanceTextProjEmbeddings.forward."""
+    dt = pooled.dtype
+    p = "time_text_embed."
+    te = _lin(sd, p + "timestep_embedder.linear_2", F.silu(_lin(sd, p + "timestep_embedder.linear_1", timestep_proj(timestep).to(dt))))
+    if cfg.guidance_embeds:
+        ge = _lin(sd, p + "guidance_embedder.linear_2", F.silu(_lin(sd, p + "guidance_embedder.linear_1", timestep_proj(guidance).to(dt))))
+        te = te + ge
+    pe = _lin(sd, p + "text_embedder.linear_2", F.silu(_lin(sd, p + "text_embedder.linear_1", pooled)))
+    return te + pe
+
+
+# ----------------------------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------------------------
+def _heads(x, H):
+    B, S, _ = x.shape
+    return x.view(B, S, H, -1).transpose(1, 2)
+
+
+def _attention(q, k, v):
+    o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
+    B, H, S, hd = o.shape
+    return o.transpose(1, 2).reshape(B, S, H * hd)
+
+
+def double_block(sd, cfg, i, hidden, enc, temb, cos, sin):
+    """[ext] transformer_flux.FluxTransformerBlock.forward + attention_processor.FluxAttnProcessor2_0."""
+    p = f"transformer_blocks.{i}."
+    H = cfg.num_attention_heads
+    act = F.silu(temb)
+    sh_msa, sc_msa, g_msa, sh_mlp, sc_mlp, g_mlp = _lin(sd, p + "norm1.linear", act).chunk(6, dim=1)
+    csh_msa, csc_msa, cg_msa, csh_mlp, csc_mlp, cg_mlp = _lin(sd, p + "norm1_context.linear", act).chunk(6, dim=1)
+    n_h = _ln(hidden) * (1 + sc_msa[:, None]) + sh_msa[:, None]
+    n_e = _ln(enc) * (1 + csc_msa[:, None]) + csh_msa[:, None]
+
+    a = p + "attn."
+    q = rms_norm(_heads(_lin(sd, a + "to_q", n_h), H), sd[a + "norm_q.weight"])
+    k = rms_norm(_heads(_lin(sd, a + "to_k", n_h), H), sd[a + "norm_k.weight"])
+    v = _heads(_lin(sd, a + "to_v", n_h), H)
+    eq = rms_norm(_heads(_lin(sd, a + "add_q_proj", n_e), H), sd[a + "norm_added_q.weight"])
+    ek = rms_norm(_heads(_lin(sd, a + "add_k_proj", n_e), H), sd[a + "norm_added_k.weight"])
+    ev = _heads(_lin(sd, a + "add_v_proj", n_e), H)
+    q = apply_rotary_emb(torch.cat([eq, q], dim=2), cos, sin)
+    k = apply_rotary_emb(torch.cat([ek, k], dim=2), cos, sin)
+    v = torch.cat([ev, v], dim=2)
+    o = _attention(q, k, v).to(q.dtype)
+    T = enc.shape[1]
+    e_attn, h_attn = o[:, :T], o[:, T:]
+    h_attn = _lin(sd, a + "to_out.0", h_attn)
+    e_attn = _lin(sd, a + "to_add_out", e_attn)
+
+    hidden = hidden + g_msa[:, None] * h_attn
+    n_h = _ln(hidden) * (1 + sc_mlp[:, None]) + sh_mlp[:, None]
+    ff = _lin(sd, p + "ff.net.2", F.gelu(_lin(sd, p + "ff.net.0.proj", n_h), approximate="tanh"))
+    hidden = hidden + g_mlp[:, None] * ff
+
+    enc = enc + cg_msa[:, None] * e_attn
+    n_e = _ln(enc) * (1 + csc_mlp[:, None]) + csh_mlp[:, None]
+    cff = _lin(sd, p + "ff_context.net.2", F.gelu(_lin(sd, p + "ff_context.net.0.proj", n_e), approximate="tanh"))
+    enc = enc + cg_mlp[:, None] * cff
+    return enc, hidden
+
+
+def single_block(sd, cfg, i, hidden, temb, cos, sin):
+    """[ext] transformer_flux.FluxSingleTransformerBlock.forward."""
+    p = f"single_transformer_blocks.{i}."
+    H = cfg.num_attention_heads
+    shift, scale, gate = _lin(sd, p + "norm.linear", F.silu(temb)).chunk(3, dim=1)
+    n = _ln(hidden) * (1 + scale[:, None]) + shift[:, None]
+    mlp = F.gelu(_lin(sd, p + "proj_mlp", n), approximate="tanh")
+    a = p + "attn."
+    q = apply_rotary_emb(rms_norm(_heads(_lin(sd, a + "to_q", n), H), sd[a + "norm_q.weight"]), cos, sin)
+    k = apply_rotary_emb(rms_norm(_heads(_lin(sd, a + "to_k", n), H), sd[a + "norm_k.weight"]), cos, sin)
+    v = _heads(_lin(sd, a + "to_v", n), H)
+    attn = _attention(q, k, v).to(q.dtype)
+    out = gate[:, None] * _lin(sd, p + "proj_out", torch.cat([attn, mlp], dim=2))
+    return hidden + out
+
+
+def transformer_forward(sd, cfg: FluxConfig, hidden, enc, pooled, timestep, img_ids, txt_ids, guidance,
+                        taps: dict = None):
+    """[ext] transformer_flux.FluxTransformer2DModel.forward.
+
+    hidden [B,S_img,64], enc [B,T,joint], pooled [B,pooled], timestep [B] in [0,1] (pipeline passes t/1000),
+    guidance [B].  Returns the velocity prediction [B,S_img,64].  `taps` collects intermediates.
+    """
+    dt = hidden.dtype
+    hidden = _lin(sd, "x_embedder", hidden)
+    timestep = timestep.to(dt) * 1000
+    guidance = guidance.to(dt) * 1000 if guidance is not None else None
+    temb = time_text_embed(sd, cfg, timestep, guidance, pooled)
+    enc = _lin(sd, "context_embedder", enc)
+    cos, sin = rope_tables(torch.cat([txt_ids, img_ids], dim=0), cfg.axes_dims_rope)
+    if taps is not None:
+        taps.update(temb=temb, x_embed=hidden, ctx_embed=enc, cos=cos, sin=sin)
+    for i in range(cfg.num_layers):
+        enc, hidden = double_block(sd, cfg, i, hidden, enc, temb, cos, sin)
+        if taps is not None:
+            taps[f"double{i}"] = torch.cat([enc, hidden], dim=1)
+    T = enc.shape[1]
+    hidden = torch.cat([enc, hidden], dim=1)
+    for i in range(cfg.num_single_layers):
+        hidden = single_block(sd, cfg, i, hidden, temb, cos, sin)
+        if taps is not None:
+            taps[f"single{i}"] = hidden
+    hidden = hidden[:, T:]
+    # [ext] normalization.AdaLayerNormContinuous: chunk order is (scale, shift)
+    scale, shift = _lin(sd, "norm_out.linear", F.silu(temb).to(dt)).chunk(2, dim=1)
+    hidden = _ln(hidden) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return _lin(sd, "proj_out", hidden)
+
+
+# ----------------------------------------------------------------------------------------------
+# pipeline glue ([ext] pipelines/flux/pipeline_flux.py, schedulers/scheduling_flow_match_euler_discrete.py)
+# ----------------------------------------------------------------------------------------------
+def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15):
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+def make_sigmas(num_steps: int, image_seq_len: int) -> np.ndarray:
+    """sigmas = linspace(1, 1/N, N); time_shift(mu, 1, s) = e^mu / (e^mu + (1/s - 1)); append 0.  float32."""
+    s = np.linspace(1.0, 1.0 / num_steps, num_steps)
+    mu = calculate_shift(image_seq_len)
+    s = math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0) ** 1.0)
+    return np.concatenate([s.astype(np.float32), np.zeros(1, dtype=np.float32)])
+
+
+def pack_latents(lat: torch.Tensor) -> torch.Tensor:
+    B, C, H, W = lat.shape
+    return lat.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), C * 4)
+
+
+def unpack_latents(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """x [B,(H/2)(W/2),C*4] -> [B,C,H,W] (H, W are LATENT sizes)."""
+    B, _, ch = x.shape
+    return x.view(B, H // 2, W // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(B, ch // 4, H, W)
+
+
+def latent_image_ids(h2: int, w2: int) -> torch.Tensor:
+    ids = torch.zeros(h2, w2, 3)
+    ids[..., 1] += torch.arange(h2)[:, None]
+    ids[..., 2] += torch.arange(w2)[None, :]
+    return ids.reshape(h2 * w2, 3)
+
+
+def effective_timestep(t: float, dtype) -> float:
+    """The scalar the sinusoid finally sees: pipeline casts t to latents.dtype, divides by 1000, the
+    transformer multiplies by 1000 again in that dtype (pipeline_flux.py __call__, transformer forward)."""
+    x = torch.tensor([t], dtype=torch.float32).to(dtype)
+    return float(((x / 1000).to(dtype) * 1000).float())
+
+
+def denoise(sd, cfg: FluxConfig, latents_packed, prompt_embeds, pooled, h2, w2, num_steps, guidance_scale=3.5,
+            trace: list = None):
+    """The FluxPipeline.__call__ loop on packed latents [B,S,64]; returns final packed latents."""
+    dt = latents_packed.dtype
+    B, S, _ = latents_packed.shape
+    sig = make_sigmas(num_steps, S)
+    timesteps = torch.from_numpy(sig[:-1]) * 1000.0
+    img_ids = latent_image_ids(h2, w2).to(dt)
+    txt_ids = torch.zeros(prompt_embeds.shape[1], 3).to(dt)
+    guidance = torch.full([1], guidance_scale, dtype=torch.float32).expand(B) if cfg.guidance_embeds else None
+    x = latents_packed
+    for i in range(num_steps):
+        t = timesteps[i].expand(B).to(dt)
+        v = transformer_forward(sd, cfg, x, prompt_embeds, pooled, t / 1000, img_ids, txt_ids, guidance)
+        x = (x.float() + float(sig[i + 1] - sig[i]) * v.float()).to(v.dtype)
+        if trace is not None:
+            trace.append(x.clone())
+    return x

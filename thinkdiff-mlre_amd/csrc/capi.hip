@@ -55,4 +55,43 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
   return td_attn_launch(p, (hipStream_t)stream);
 }
 
+int td_norm_rows_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, int rms, float eps,
+                      const void* w, int split, const void* shiftA, const void* scaleA,
+                      const void* shiftB, const void* scaleB, void* stream) {
+  TdNormParams p;
+  p.x = (const bf16_t*)x; p.ldx = (int)ldx; p.y = (bf16_t*)y; p.ldy = (int)ldy; p.rows = rows; p.D = D;
+  p.rms = rms; p.eps = eps; p.w = (const bf16_t*)w; p.split = split;
+  p.shiftA = (const bf16_t*)shiftA; p.scaleA = (const bf16_t*)scaleA;
+  p.shiftB = (const bf16_t*)shiftB; p.scaleB = (const bf16_t*)scaleB;
+  if (p.scaleA && !p.scaleB) { p.scaleB = p.scaleA; p.shiftB = p.shiftA; }
+  return td_norm_rows_launch(p, (hipStream_t)stream);
+}
+
+int td_qk_norm_rope_bf16(void* qkv, int64_t ld, int rows, int Hq, int Hk, int q_col, int k_col,
+                         const float* cos, const float* sin, int split, const void* wqA, const void* wkA,
+                         const void* wqB, const void* wkB, float eps, int rotate_half, void* stream) {
+  TdQkRopeParams p;
+  p.qkv = (bf16_t*)qkv; p.ld = (int)ld; p.rows = rows; p.Hq = Hq; p.Hk = Hk; p.q_col = q_col; p.k_col = k_col;
+  p.cos = cos; p.sin = sin; p.split = split;
+  p.wqA = (const bf16_t*)wqA; p.wkA = (const bf16_t*)wkA; p.wqB = (const bf16_t*)wqB; p.wkB = (const bf16_t*)wkB;
+  p.eps = eps; p.rotate_half = rotate_half;
+  return td_qk_norm_rope_launch(p, (hipStream_t)stream);
+}
+
+int td_flux_rope_table(const float* ids, int S, const int* axes_dims3, double theta, float* cos, float* sin, void* stream) {
+  return td_flux_rope_table_launch(ids, S, axes_dims3, theta, cos, sin, (hipStream_t)stream);
+}
+int td_timestep_sincos(const float* t, int n, void* out, void* stream) {
+  return td_timestep_sincos_launch(t, n, (bf16_t*)out, (hipStream_t)stream);
+}
+int td_euler_step_bf16(void* x, const void* v, float dt, int64_t n, void* stream) {
+  return td_euler_step_launch((bf16_t*)x, (const bf16_t*)v, dt, n, (hipStream_t)stream);
+}
+int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float mul, float add, void* stream) {
+  return td_flux_pack_launch((const bf16_t*)src, (bf16_t*)dst, C, H, W, unpack, mul, add, (hipStream_t)stream);
+}
+int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream) {
+  return td_cls_avgpool2_launch((const bf16_t*)x, (bf16_t*)y, G, C, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,326 @@
+// HBM-bound row kernels of the FLUX / aligner / Qwen2-VL path (SURVEY.md 2.3 K3,K5,K7,K9,K10,K16,K17,K20).
+// All bf16 traffic is 16 B per lane (guide G13); statistics, RoPE and the Euler update are fp32.
+// Rounding points mirror the reference's bf16 torch pipeline (each torch op rounds to bf16).
+#include "td_common.h"
+#include "td_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = bf_lo(v[i]);
+    f[2 * i + 1] = bf_hi(v[i]);
+  }
+}
+__device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Row normalisation (+ optional affine weight, + optional adaLN modulation), one wave per row.
+//   LayerNorm (no affine, eps) : n = (x - mean) * rsqrt(var + eps)          [diffusers AdaLayerNorm*]
+//   RMSNorm                   : n = x * rsqrt(mean(x^2) + eps)             [T5LayerNorm / Qwen2RMSNorm]
+//   y = bf16(n); if w: y = bf16(w*y); if mod: y = bf16(bf16(y * bf16(1+scale)) + shift)
+// Rows < split use (shiftA, scaleA), rows >= split use (shiftB, scaleB): the joint [text||image]
+// buffer is normalised in one launch although the two streams carry different modulations.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const bf16_t* xr = p.x + (size_t)row * p.ldx;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    unpack8(*(const u32x4_t*)(xr + c * 512 + lane * 8), v[c]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += v[c][i];
+  }
+  constexpr float inv_d = 1.0f / (NCH * 512);
+  float mean = 0.f;
+  if (!p.rms) mean = wave_sum(sum) * inv_d;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[c][i] -= mean;
+      sq += v[c][i] * v[c][i];
+    }
+  const float rstd = rsqrtf(wave_sum(sq) * inv_d + p.eps);
+
+  const bool partB = row >= p.split;
+  const bf16_t* shift = partB ? p.shiftB : p.shiftA;
+  const bf16_t* scale = partB ? p.scaleB : p.scaleA;
+  bf16_t* yr = p.y + (size_t)row * p.ldy;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = rbf(v[c][i] * rstd);
+    if (p.w) {
+      float w[8];
+      unpack8(*(const u32x4_t*)(p.w + col), w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = rbf(y[i] * w[i]);
+    }
+    if (scale) {
+      float sc[8], sh[8];
+      unpack8(*(const u32x4_t*)(scale + col), sc);
+      unpack8(*(const u32x4_t*)(shift + col), sh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = rbf(rbf(y[i] * rbf(1.0f + sc[i])) + sh[i]);
+    }
+    *(u32x4_t*)(yr + col) = pack8(y);
+  }
+}
+
+int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream) {
+  TD_CHECK_ARG(p.rows > 0 && p.D > 0, "td_norm_rows: empty problem");
+  TD_CHECK_ARG(p.D % 512 == 0 && p.D <= 4096, "td_norm_rows: D=%d must be a multiple of 512, <= 4096", p.D);
+  TD_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0, "td_norm_rows: row strides must be multiples of 8");
+  TD_CHECK_ARG((p.scaleA == nullptr) == (p.shiftA == nullptr), "td_norm_rows: shift and scale come together");
+  const dim3 grid((p.rows + 3) / 4), block(256);
+  switch (p.D / 512) {
+#define TD_CASE(n) case n: hipLaunchKernelGGL(td_norm_rows_kernel<n>, grid, block, 0, stream, p); break;
+    TD_CASE(1) TD_CASE(2) TD_CASE(3) TD_CASE(4) TD_CASE(5) TD_CASE(6) TD_CASE(7) TD_CASE(8)
+#undef TD_CASE
+  }
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-head q/k RMSNorm (eps, learned weight[128]) followed by rotary embedding, in place on the
+// fused projection buffer.  16 lanes own one 128-wide head row (8 elements each).
+//   FLUX  : interleaved pairs (2i, 2i+1), cos/sin tables [S,128] fp32 (repeat-interleaved)
+//           [ext diffusers embeddings.apply_rotary_emb use_real_unbind_dim=-1]
+//   Qwen2 : rotate_half (i, i+64), tables [S,128] fp32 already M-RoPE-section-merged; no q/k norm
+//           (transformers modeling_qwen2_vl.py:180-222)
+// Rows < split take the (wqA, wkA) norm weights (FLUX norm_added_q/k for text tokens), the rest
+// (wqB, wkB) (norm_q/k).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void td_qk_norm_rope_kernel(const TdQkRopeParams p) {
+  const int row = blockIdx.x;
+  const int l16 = threadIdx.x & 15;
+  const int unit0 = threadIdx.x >> 4;  // 16 head-units per pass
+  const int nunits = p.Hq + p.Hk;
+  bf16_t* base = p.qkv + (size_t)row * p.ld;
+  const bool partB = row >= p.split;
+  const bf16_t* wq = partB ? p.wqB : p.wqA;
+  const bf16_t* wk = partB ? p.wkB : p.wkA;
+
+  float cs[8], sn[8];
+  {
+    const float* cr = p.cos + (size_t)row * 128;
+    const float* sr = p.sin + (size_t)row * 128;
+    const int d0 = l16 * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i += 4) {
+      const f32x4_t c4 = *(const f32x4_t*)(cr + d0 + i);
+      const f32x4_t s4 = *(const f32x4_t*)(sr + d0 + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cs[i + j] = c4[j];
+        sn[i + j] = s4[j];
+      }
+    }
+  }
+
+  for (int u = unit0; u < nunits; u += 16) {
+    const bool is_k = u >= p.Hq;
+    bf16_t* hp = base + (is_k ? p.k_col + (u - p.Hq) * 128 : p.q_col + u * 128) + l16 * 8;
+    float x[8];
+    unpack8(*(const u32x4_t*)hp, x);
+    const bf16_t* w = is_k ? wk : wq;
+    if (w) {
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sq += x[i] * x[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
+      const float rstd = rsqrtf(sq * (1.0f / 128.0f) + p.eps);
+      float wv[8];
+      unpack8(*(const u32x4_t*)(w + l16 * 8), wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = rbf(rbf(x[i] * rstd) * wv[i]);
+    }
+    float y[8];
+    if (p.rotate_half) {
+      // partner element i+64 (or i-64) lives 8 lanes away
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float other = __shfl_xor(x[i], 8, 16);
+        const float rot = (l16 < 8) ? -other : other;
+        y[i] = x[i] * cs[i] + rot * sn[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        y[i] = x[i] * cs[i] - x[i + 1] * sn[i];
+        y[i + 1] = x[i + 1] * cs[i + 1] + x[i] * sn[i + 1];
+      }
+    }
+    *(u32x4_t*)hp = pack8(y);
+  }
+}
+
+int td_qk_norm_rope_launch(const TdQkRopeParams& p, hipStream_t stream) {
+  TD_CHECK_ARG(p.rows > 0 && p.Hq > 0 && p.Hk >= 0, "td_qk_norm_rope: empty problem");
+  TD_CHECK_ARG(p.ld % 8 == 0 && p.q_col % 8 == 0 && p.k_col % 8 == 0, "td_qk_norm_rope: columns must be 16-byte aligned");
+  hipLaunchKernelGGL(td_qk_norm_rope_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FluxPosEmbed: cos/sin[S,128] fp32 from ids[S,3]; per axis a with dim d_a: freq_j = theta^(-2j/d_a)
+// in fp64, angle = id * freq, cos/sin -> fp32, each value repeated for the pair (2j, 2j+1).
+// [ext diffusers embeddings.get_1d_rotary_pos_embed(repeat_interleave_real=True, freqs_dtype=float64)]
+// ---------------------------------------------------------------------------------------------
+__global__ void td_flux_rope_table_kernel(const float* ids, int S, int d0, int d1, int d2, double theta, float* cosT, float* sinT) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = (d0 + d1 + d2) / 2;
+  if (idx >= S * half) return;
+  const int s = idx / half, j = idx % half;
+  int axis, jj, dim;
+  if (j < d0 / 2) { axis = 0; jj = j; dim = d0; }
+  else if (j < (d0 + d1) / 2) { axis = 1; jj = j - d0 / 2; dim = d1; }
+  else { axis = 2; jj = j - (d0 + d1) / 2; dim = d2; }
+  const double freq = 1.0 / pow(theta, (double)(2 * jj) / (double)dim);
+  const double ang = (double)ids[s * 3 + axis] * freq;
+  const float c = (float)cos(ang), sn = (float)sin(ang);
+  const size_t o = (size_t)s * (2 * half) + 2 * j;
+  cosT[o] = c; cosT[o + 1] = c;
+  sinT[o] = sn; sinT[o + 1] = sn;
+}
+
+int td_flux_rope_table_launch(const float* ids, int S, const int* axes, double theta, float* cosT, float* sinT, hipStream_t stream) {
+  TD_CHECK_ARG(S > 0 && axes[0] + axes[1] + axes[2] == 128, "td_flux_rope_table: axes dims must sum to 128");
+  const int n = S * 64;
+  hipLaunchKernelGGL(td_flux_rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, S, axes[0], axes[1], axes[2], theta, cosT, sinT);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): out[n] = [cos(t f_j) | sin(t f_j)],
+// f_j = exp(-ln(1e4) j / 128), fp32 math, bf16 out.   [ext diffusers embeddings.get_timestep_embedding]
+// ---------------------------------------------------------------------------------------------
+__global__ void td_timestep_sincos_kernel(const float* t, int n, bf16_t* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * 128) return;
+  const int r = idx / 128, j = idx % 128;
+  const float f = expf(-9.210340371976184f * (float)j / 128.0f);
+  const float a = t[r] * f;
+  out[r * 256 + j] = f2bf(cosf(a));
+  out[r * 256 + 128 + j] = f2bf(sinf(a));
+}
+
+int td_timestep_sincos_launch(const float* t, int n, bf16_t* out, hipStream_t stream) {
+  TD_CHECK_ARG(n > 0, "td_timestep_sincos: n must be positive");
+  hipLaunchKernelGGL(td_timestep_sincos_kernel, dim3((n * 128 + 255) / 256), dim3(256), 0, stream, t, n, out);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// temb[r] = bf16(bf16(te[r] + ge) + pe); out = silu(temb) (bf16).  te:[n,D], ge,pe:[D]
+// [ext CombinedTimestepGuidanceTextProjEmbeddings.forward, then the nn.SiLU of every AdaLayerNorm*]
+__global__ void td_temb_combine_silu_kernel(const bf16_t* te, const bf16_t* ge, const bf16_t* pe, int n, int D, bf16_t* temb, bf16_t* silu_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * D) return;
+  const int c = idx % D;
+  float v = bf2f(te[idx]);
+  if (ge) v = rbf(v + bf2f(ge[c]));
+  v = rbf(v + bf2f(pe[c]));
+  if (temb) temb[idx] = f2bf(v);
+  silu_out[idx] = f2bf(silu_f(v));
+}
+
+int td_temb_combine_silu_launch(const bf16_t* te, const bf16_t* ge, const bf16_t* pe, int n, int D, bf16_t* temb, bf16_t* silu_out, hipStream_t stream) {
+  TD_CHECK_ARG(n > 0 && D > 0, "td_temb_combine_silu: empty problem");
+  hipLaunchKernelGGL(td_temb_combine_silu_kernel, dim3((n * D + 255) / 256), dim3(256), 0, stream, te, ge, pe, n, D, temb, silu_out);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// FlowMatchEulerDiscreteScheduler.step: x = bf16(float(x) + dt * float(v))   [ext scheduling_flow_match_euler_discrete.py]
+__global__ void td_euler_step_kernel(bf16_t* x, const bf16_t* v, float dt, int n8) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  float a[8], b[8];
+  unpack8(((const u32x4_t*)x)[idx], a);
+  unpack8(((const u32x4_t*)v)[idx], b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = a[i] + dt * b[i];
+  ((u32x4_t*)x)[idx] = pack8(a);
+}
+
+int td_euler_step_launch(bf16_t* x, const bf16_t* v, float dt, long long n, hipStream_t stream) {
+  TD_CHECK_ARG(n > 0 && n % 8 == 0, "td_euler_step: n=%lld must be a positive multiple of 8", n);
+  const int n8 = (int)(n / 8);
+  hipLaunchKernelGGL(td_euler_step_kernel, dim3((n8 + 255) / 256), dim3(256), 0, stream, x, v, dt, n8);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// FluxPipeline._pack_latents / _unpack_latents: [C,H,W] <-> [(H/2)(W/2), C*4], token (i,j) holds
+// x[c, 2i+di, 2j+dj] at column c*4 + di*2 + dj.  Unpack optionally applies z/scaling + shift (the
+// pre-VAE affine of FluxPipeline.__call__).  One thread per token row element pair.
+__global__ void td_flux_pack_kernel(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = C * H * W;
+  if (idx >= total) return;
+  // idx enumerates the packed layout so the packed side is the coalesced one
+  const int cols = C * 4;
+  const int tok = idx / cols, col = idx % cols;
+  const int c = col >> 2, di = (col >> 1) & 1, dj = col & 1;
+  const int wj = W / 2;
+  const int i = tok / wj, j = tok % wj;
+  const size_t sp = ((size_t)c * H + (2 * i + di)) * W + (2 * j + dj);
+  if (unpack) dst[sp] = f2bf(bf2f(src[idx]) * mul + add);
+  else dst[idx] = src[sp];
+}
+
+int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add, hipStream_t stream) {
+  TD_CHECK_ARG(C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "td_flux_pack: bad latent shape %dx%dx%d", C, H, W);
+  const int total = C * H * W;
+  hipLaunchKernelGGL(td_flux_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, src, dst, C, H, W, unpack, mul, add);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ThinkDiff-CLIP token pooling: tokens [1+G*G, C] -> [1+(G/2)^2, C]; CLS row copied, the G x G grid
+// reduced by 2x2 mean ( == F.interpolate(bilinear, align_corners=False) at exactly 2x, fp32 math
+// then bf16).  thinkdiff/models/blip_vision_t5_decoder.py:620-637
+__global__ void td_cls_avgpool2_kernel(const bf16_t* x, bf16_t* y, int G, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g2 = G / 2;
+  const int total = (1 + g2 * g2) * C;
+  if (idx >= total) return;
+  const int tok = idx / C, c = idx % C;
+  if (tok == 0) { y[idx] = x[c]; return; }
+  const int i = (tok - 1) / g2, j = (tok - 1) % g2;
+  auto at = [&](int r, int s) { return bf2f(x[(size_t)(1 + r * G + s) * C + c]); };
+  // bilinear with align_corners=False at scale 2 samples (2i+0.5, 2j+0.5): weights 0.5/0.5 per axis
+  const float top = 0.5f * at(2 * i, 2 * j) + 0.5f * at(2 * i, 2 * j + 1);
+  const float bot = 0.5f * at(2 * i + 1, 2 * j) + 0.5f * at(2 * i + 1, 2 * j + 1);
+  y[idx] = f2bf(0.5f * top + 0.5f * bot);
+}
+
+int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t stream) {
+  TD_CHECK_ARG(G > 0 && G % 2 == 0 && C > 0, "td_cls_avgpool2: grid %d must be even", G);
+  const int total = (1 + (G / 2) * (G / 2)) * C;
+  hipLaunchKernelGGL(td_cls_avgpool2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, x, y, G, C);
+  TD_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,476 @@
+// FLUX.1 MMDiT denoise engine: host-side C++ that owns the fused weight arena + activation
+// workspace in HBM and issues the per-step kernel sequence (one stream, no host sync, no
+// allocation after creation).
+//
+// Replaces, for the ThinkDiff drivers' `diffusion_pipe(prompt_embeds=..., pooled_prompt_embeds=...)`
+// call (reference scripts/test/test_blip_vision_t5_decoder_flux_text.py:234-242,
+// scripts/test/test_mllama_t5_decoder_flux.py:182-192):
+//   [ext diffusers 0.31.0] FluxTransformer2DModel.forward, FluxPosEmbed,
+//   CombinedTimestepGuidanceTextProjEmbeddings, AdaLayerNormZero(/Single/Continuous),
+//   FluxAttnProcessor2_0, FlowMatchEulerDiscreteScheduler.step.
+//
+// MI355X-first layout decisions
+//  * text and image streams live in ONE token-major buffer h[S = T + S_img, D] (text rows first,
+//    the order diffusers concatenates them for attention), so the double-stream blocks, the joint
+//    attention and the single-stream blocks need no concat / split copies;
+//  * q|k|v (and the single blocks' proj_mlp) are one fused projection; attention reads heads in
+//    place and writes straight into the [attn | mlp] operand of proj_out;
+//  * all 2*19 + 38 + 1 adaLN modulation linears depend only on temb(t): they are ONE weight matrix
+//    [NMOD, D] evaluated for ALL timesteps of the schedule in a single GEMM before the loop
+//    (reads 6.5 GB of modulation weights once per image instead of once per step);
+//  * bias / GELU / gate*x + residual are GEMM epilogues; LayerNorm+modulate and QK-RMSNorm+RoPE are
+//    single-pass row kernels.
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "td_kernels.h"
+#include "../../include/thinkdiff_hip.h"
+
+namespace {
+
+struct Slot {
+  std::string name;
+  bf16_t* ptr;
+  int64_t count;
+};
+
+struct DoubleW {
+  bf16_t *qkv_img_w, *qkv_img_b, *qkv_ctx_w, *qkv_ctx_b;
+  bf16_t *out_img_w, *out_img_b, *out_ctx_w, *out_ctx_b;
+  bf16_t *ff1_img_w, *ff1_img_b, *ff2_img_w, *ff2_img_b;
+  bf16_t *ff1_ctx_w, *ff1_ctx_b, *ff2_ctx_w, *ff2_ctx_b;
+  bf16_t *norm_q, *norm_k, *norm_added_q, *norm_added_k;
+};
+struct SingleW {
+  bf16_t *w1, *b1;  // [3D + M, D] = to_q | to_k | to_v | proj_mlp
+  bf16_t *w2, *b2;  // proj_out [D, D + M]
+  bf16_t *norm_q, *norm_k;
+};
+
+}  // namespace
+
+struct td_flux {
+  TdFluxConfig cfg;
+  int D = 0, M = 0, NMOD = 0;
+  int max_img = 0, max_txt = 0, max_steps = 0;
+  // weights
+  bf16_t* arena = nullptr;
+  int64_t arena_elems = 0;
+  std::vector<Slot> slots;
+  std::unordered_map<std::string, int> index;
+  bf16_t *x_w, *x_b, *ctx_w, *ctx_b, *t1_w, *t1_b, *t2_w, *t2_b, *g1_w, *g1_b, *g2_w, *g2_b, *p1_w, *p1_b, *p2_w, *p2_b;
+  bf16_t *mod_w, *mod_b, *proj_w, *proj_b;
+  std::vector<DoubleW> dbl;
+  std::vector<SingleW> sgl;
+  // workspace
+  char* ws = nullptr;
+  bf16_t *h, *xn, *qkv, *attn, *mlp, *cat, *ctx, *vout;
+  bf16_t *tproj, *tmid, *te, *gproj, *gmid, *ge, *pmid, *pe, *temb, *st, *mods;
+  float *cosT, *sinT, *ids, *tvals;
+  // state
+  int T = 0, S_img = 0, n_steps = 0;
+  bool cond_set = false;
+};
+
+namespace {
+
+struct ArenaPlan {
+  int64_t off = 0;
+  std::vector<std::pair<bf16_t**, int64_t>> fix;  // pointer-to-fill, offset
+  void take(bf16_t** p, int64_t n) {
+    fix.emplace_back(p, off);
+    off += (n + 127) & ~int64_t(127);  // 256-byte aligned tensors
+  }
+};
+
+void add_slot(td_flux* f, const std::string& name, bf16_t* ptr, int64_t count) {
+  f->index[name] = (int)f->slots.size();
+  f->slots.push_back({name, ptr, count});
+}
+
+// registers "<name>.weight" / "<name>.bias" of a Linear living at rows [row0, row0+out) of a fused matrix
+void add_linear(td_flux* f, const std::string& name, bf16_t* w, bf16_t* b, int64_t row0, int64_t out, int64_t in) {
+  add_slot(f, name + ".weight", w + row0 * in, out * in);
+  add_slot(f, name + ".bias", b + row0, out);
+}
+
+int gemm(td_flux* f, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* b, bf16_t* C, int ldc,
+         int M, int N, int K, int act = TD_ACT_NONE, const bf16_t* gate = nullptr, const bf16_t* res = nullptr, int ldr = 0) {
+  TdGemmParams p;
+  p.A = A; p.lda = lda; p.W = W; p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
+  return td_gemm_launch(p, s);
+}
+
+// N may exceed the 4 GiB buffer-descriptor range of W (the fused modulation matrix is 6.5 GB):
+// walk it in column chunks.
+int gemm_big_n(td_flux* f, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* b, bf16_t* C, int ldc,
+               int M, int64_t N, int K) {
+  const int64_t chunk = 131072;
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int nn = (int)(N - n0 < chunk ? N - n0 : chunk);
+    int rc = gemm(f, s, A, lda, W + n0 * K, b + n0, C + n0, ldc, M, nn, K);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+#define TD_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int td_flux_create(const TdFluxConfig* cfg, int max_img_tokens, int max_txt_tokens, int max_steps, td_flux** out) {
+  TD_CHECK_ARG(cfg && out, "td_flux_create: null argument");
+  TD_CHECK_ARG(cfg->head_dim == 128, "td_flux_create: head_dim must be 128");
+  TD_CHECK_ARG(cfg->axes_dims[0] + cfg->axes_dims[1] + cfg->axes_dims[2] == 128, "td_flux_create: rope axes must sum to 128");
+  TD_CHECK_ARG(cfg->in_channels % 64 == 0 && cfg->joint_dim % 64 == 0 && cfg->pooled_dim % 64 == 0, "td_flux_create: input widths must be multiples of 64");
+  TD_CHECK_ARG((cfg->num_heads * 128) % 512 == 0, "td_flux_create: inner dim must be a multiple of 512");
+  TD_CHECK_ARG(max_img_tokens > 0 && max_txt_tokens > 0 && max_steps > 0, "td_flux_create: capacities must be positive");
+  td_flux* f = new td_flux();
+  f->cfg = *cfg;
+  const int D = f->D = cfg->num_heads * cfg->head_dim;
+  const int M = f->M = cfg->mlp_ratio * D;
+  const int L = cfg->num_layers, Ls = cfg->num_single_layers;
+  f->NMOD = L * 12 * D + Ls * 3 * D + 2 * D;
+  f->max_img = max_img_tokens; f->max_txt = max_txt_tokens; f->max_steps = max_steps;
+  f->dbl.resize(L);
+  f->sgl.resize(Ls);
+
+  // ---- weight arena ---------------------------------------------------------------------------
+  ArenaPlan ap;
+  ap.take(&f->x_w, (int64_t)D * cfg->in_channels); ap.take(&f->x_b, D);
+  ap.take(&f->ctx_w, (int64_t)D * cfg->joint_dim); ap.take(&f->ctx_b, D);
+  ap.take(&f->t1_w, (int64_t)D * 256); ap.take(&f->t1_b, D);
+  ap.take(&f->t2_w, (int64_t)D * D); ap.take(&f->t2_b, D);
+  ap.take(&f->g1_w, (int64_t)D * 256); ap.take(&f->g1_b, D);
+  ap.take(&f->g2_w, (int64_t)D * D); ap.take(&f->g2_b, D);
+  ap.take(&f->p1_w, (int64_t)D * cfg->pooled_dim); ap.take(&f->p1_b, D);
+  ap.take(&f->p2_w, (int64_t)D * D); ap.take(&f->p2_b, D);
+  ap.take(&f->mod_w, (int64_t)f->NMOD * D); ap.take(&f->mod_b, f->NMOD);
+  ap.take(&f->proj_w, (int64_t)cfg->in_channels * D); ap.take(&f->proj_b, cfg->in_channels);
+  for (auto& w : f->dbl) {
+    ap.take(&w.qkv_img_w, (int64_t)3 * D * D); ap.take(&w.qkv_img_b, 3 * D);
+    ap.take(&w.qkv_ctx_w, (int64_t)3 * D * D); ap.take(&w.qkv_ctx_b, 3 * D);
+    ap.take(&w.out_img_w, (int64_t)D * D); ap.take(&w.out_img_b, D);
+    ap.take(&w.out_ctx_w, (int64_t)D * D); ap.take(&w.out_ctx_b, D);
+    ap.take(&w.ff1_img_w, (int64_t)M * D); ap.take(&w.ff1_img_b, M);
+    ap.take(&w.ff2_img_w, (int64_t)D * M); ap.take(&w.ff2_img_b, D);
+    ap.take(&w.ff1_ctx_w, (int64_t)M * D); ap.take(&w.ff1_ctx_b, M);
+    ap.take(&w.ff2_ctx_w, (int64_t)D * M); ap.take(&w.ff2_ctx_b, D);
+    ap.take(&w.norm_q, 128); ap.take(&w.norm_k, 128); ap.take(&w.norm_added_q, 128); ap.take(&w.norm_added_k, 128);
+  }
+  for (auto& w : f->sgl) {
+    ap.take(&w.w1, (int64_t)(3 * D + M) * D); ap.take(&w.b1, 3 * D + M);
+    ap.take(&w.w2, (int64_t)D * (D + M)); ap.take(&w.b2, D);
+    ap.take(&w.norm_q, 128); ap.take(&w.norm_k, 128);
+  }
+  f->arena_elems = ap.off;
+  hipError_t e = hipMalloc((void**)&f->arena, (size_t)ap.off * sizeof(bf16_t));
+  if (e != hipSuccess) {
+    td_set_error("td_flux_create: hipMalloc of %.2f GiB weight arena failed: %s", ap.off * 2.0 / (1 << 30), hipGetErrorString(e));
+    delete f;
+    return TD_ERR_HIP;
+  }
+  for (auto& fx : ap.fix) *fx.first = f->arena + fx.second;
+
+  // ---- parameter table under the diffusers state-dict names ----------------------------------------
+  add_linear(f, "x_embedder", f->x_w, f->x_b, 0, D, cfg->in_channels);
+  add_linear(f, "context_embedder", f->ctx_w, f->ctx_b, 0, D, cfg->joint_dim);
+  add_linear(f, "time_text_embed.timestep_embedder.linear_1", f->t1_w, f->t1_b, 0, D, 256);
+  add_linear(f, "time_text_embed.timestep_embedder.linear_2", f->t2_w, f->t2_b, 0, D, D);
+  if (cfg->guidance_embeds) {
+    add_linear(f, "time_text_embed.guidance_embedder.linear_1", f->g1_w, f->g1_b, 0, D, 256);
+    add_linear(f, "time_text_embed.guidance_embedder.linear_2", f->g2_w, f->g2_b, 0, D, D);
+  }
+  add_linear(f, "time_text_embed.text_embedder.linear_1", f->p1_w, f->p1_b, 0, D, cfg->pooled_dim);
+  add_linear(f, "time_text_embed.text_embedder.linear_2", f->p2_w, f->p2_b, 0, D, D);
+  for (int i = 0; i < L; ++i) {
+    const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+    DoubleW& w = f->dbl[i];
+    add_linear(f, p + "norm1.linear", f->mod_w, f->mod_b, (int64_t)i * 12 * D, 6 * D, D);
+    add_linear(f, p + "norm1_context.linear", f->mod_w, f->mod_b, (int64_t)i * 12 * D + 6 * D, 6 * D, D);
+    add_linear(f, p + "attn.to_q", w.qkv_img_w, w.qkv_img_b, 0, D, D);
+    add_linear(f, p + "attn.to_k", w.qkv_img_w, w.qkv_img_b, D, D, D);
+    add_linear(f, p + "attn.to_v", w.qkv_img_w, w.qkv_img_b, 2 * D, D, D);
+    add_linear(f, p + "attn.add_q_proj", w.qkv_ctx_w, w.qkv_ctx_b, 0, D, D);
+    add_linear(f, p + "attn.add_k_proj", w.qkv_ctx_w, w.qkv_ctx_b, D, D, D);
+    add_linear(f, p + "attn.add_v_proj", w.qkv_ctx_w, w.qkv_ctx_b, 2 * D, D, D);
+    add_linear(f, p + "attn.to_out.0", w.out_img_w, w.out_img_b, 0, D, D);
+    add_linear(f, p + "attn.to_add_out", w.out_ctx_w, w.out_ctx_b, 0, D, D);
+    add_slot(f, p + "attn.norm_q.weight", w.norm_q, 128);
+    add_slot(f, p + "attn.norm_k.weight", w.norm_k, 128);
+    add_slot(f, p + "attn.norm_added_q.weight", w.norm_added_q, 128);
+    add_slot(f, p + "attn.norm_added_k.weight", w.norm_added_k, 128);
+    add_linear(f, p + "ff.net.0.proj", w.ff1_img_w, w.ff1_img_b, 0, M, D);
+    add_linear(f, p + "ff.net.2", w.ff2_img_w, w.ff2_img_b, 0, D, M);
+    add_linear(f, p + "ff_context.net.0.proj", w.ff1_ctx_w, w.ff1_ctx_b, 0, M, D);
+    add_linear(f, p + "ff_context.net.2", w.ff2_ctx_w, w.ff2_ctx_b, 0, D, M);
+  }
+  for (int i = 0; i < Ls; ++i) {
+    const std::string p = "single_transformer_blocks." + std::to_string(i) + ".";
+    SingleW& w = f->sgl[i];
+    add_linear(f, p + "norm.linear", f->mod_w, f->mod_b, (int64_t)L * 12 * D + (int64_t)i * 3 * D, 3 * D, D);
+    add_linear(f, p + "attn.to_q", w.w1, w.b1, 0, D, D);
+    add_linear(f, p + "attn.to_k", w.w1, w.b1, D, D, D);
+    add_linear(f, p + "attn.to_v", w.w1, w.b1, 2 * D, D, D);
+    add_linear(f, p + "proj_mlp", w.w1, w.b1, 3 * D, M, D);
+    add_linear(f, p + "proj_out", w.w2, w.b2, 0, D, D + M);
+    add_slot(f, p + "attn.norm_q.weight", w.norm_q, 128);
+    add_slot(f, p + "attn.norm_k.weight", w.norm_k, 128);
+  }
+  add_linear(f, "norm_out.linear", f->mod_w, f->mod_b, (int64_t)L * 12 * D + (int64_t)Ls * 3 * D, 2 * D, D);
+  add_linear(f, "proj_out", f->proj_w, f->proj_b, 0, cfg->in_channels, D);
+
+  // ---- activation workspace -----------------------------------------------------------------------
+  const int64_t S = (int64_t)max_img_tokens + max_txt_tokens;
+  const int64_t n = max_steps;
+  struct Req { void** p; int64_t bytes; };
+  std::vector<Req> reqs = {
+      {(void**)&f->h, S * D * 2}, {(void**)&f->xn, S * D * 2}, {(void**)&f->qkv, S * 3 * D * 2},
+      {(void**)&f->attn, S * D * 2}, {(void**)&f->mlp, S * M * 2}, {(void**)&f->cat, S * (D + M) * 2},
+      {(void**)&f->ctx, (int64_t)max_txt_tokens * D * 2}, {(void**)&f->vout, (int64_t)max_img_tokens * cfg->in_channels * 2},
+      {(void**)&f->tproj, n * 256 * 2}, {(void**)&f->tmid, n * D * 2}, {(void**)&f->te, n * D * 2},
+      {(void**)&f->gproj, 256 * 2}, {(void**)&f->gmid, (int64_t)D * 2}, {(void**)&f->ge, (int64_t)D * 2},
+      {(void**)&f->pmid, (int64_t)D * 2}, {(void**)&f->pe, (int64_t)D * 2},
+      {(void**)&f->temb, n * D * 2}, {(void**)&f->st, n * D * 2}, {(void**)&f->mods, n * (int64_t)f->NMOD * 2},
+      {(void**)&f->cosT, S * 128 * 4}, {(void**)&f->sinT, S * 128 * 4}, {(void**)&f->ids, S * 3 * 4},
+      {(void**)&f->tvals, (n + 1) * 4},
+  };
+  int64_t total = 0;
+  for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
+  e = hipMalloc((void**)&f->ws, (size_t)total);
+  if (e != hipSuccess) {
+    td_set_error("td_flux_create: hipMalloc of %.2f GiB workspace failed: %s", total / double(1 << 30), hipGetErrorString(e));
+    (void)hipFree(f->arena);
+    delete f;
+    return TD_ERR_HIP;
+  }
+  (void)hipMemset(f->ws, 0, (size_t)total);
+  int64_t o = 0;
+  for (auto& r : reqs) {
+    *r.p = f->ws + o;
+    o += (r.bytes + 255) & ~int64_t(255);
+  }
+  *out = f;
+  return TD_OK;
+}
+
+void td_flux_destroy(td_flux* f) {
+  if (!f) return;
+  (void)hipFree(f->arena);
+  (void)hipFree(f->ws);
+  delete f;
+}
+
+int64_t td_flux_param_elems(const td_flux* f) { return f ? f->arena_elems : 0; }
+int td_flux_num_params(const td_flux* f) { return f ? (int)f->slots.size() : 0; }
+
+int td_flux_param_info(const td_flux* f, int idx, char* name_buf, int buf_len, int64_t* count) {
+  TD_CHECK_ARG(f && idx >= 0 && idx < (int)f->slots.size(), "td_flux_param_info: index %d out of range", idx);
+  const Slot& s = f->slots[idx];
+  if (name_buf && buf_len > 0) {
+    strncpy(name_buf, s.name.c_str(), buf_len - 1);
+    name_buf[buf_len - 1] = 0;
+  }
+  if (count) *count = s.count;
+  return TD_OK;
+}
+
+int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t count, void* stream) {
+  TD_CHECK_ARG(f && name && src, "td_flux_load_param: null argument");
+  auto it = f->index.find(name);
+  TD_CHECK_ARG(it != f->index.end(), "td_flux_load_param: unknown parameter '%s'", name);
+  const Slot& s = f->slots[it->second];
+  TD_CHECK_ARG(s.count == count, "td_flux_load_param: '%s' expects %lld elements, got %lld", name, (long long)s.count, (long long)count);
+  TD_CHECK_HIP(hipMemcpyAsync(s.ptr, src, (size_t)count * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TD_OK;
+}
+
+}  // extern "C"
+
+// ---- synthetic checkpoint: counter-based N(0, std) (full-shape random init for throughput runs) ------
+__global__ void td_fill_normal_kernel(bf16_t* dst, long long n, unsigned long long seed, float std, float mean) {
+  const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * pair >= n) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(pair + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u1 = ((unsigned)(z >> 40) + 1.0f) * (1.0f / 16777217.0f);
+  const float u2 = (unsigned)((z >> 8) & 0xffffff) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincosf(6.283185307179586f * u2, &s, &c);
+  dst[2 * pair] = f2bf(mean + std * r * c);
+  if (2 * pair + 1 < n) dst[2 * pair + 1] = f2bf(mean + std * r * s);
+}
+
+extern "C" {
+
+int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float mean, void* stream) {
+  TD_CHECK_ARG(dst && n > 0, "td_fill_normal_bf16: empty buffer");
+  const long long pairs = (n + 1) / 2;
+  hipLaunchKernelGGL(td_fill_normal_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)dst, (long long)n, (unsigned long long)seed, std, mean);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream) {
+  TD_CHECK_ARG(f, "td_flux_init_random: null handle");
+  TD_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
+  for (const Slot& s : f->slots)
+    if (s.count == 128 && s.name.find(".norm_") != std::string::npos)
+      TD_TRY(td_fill_normal_bf16(s.ptr, s.count, seed ^ (uint64_t)(uintptr_t)s.ptr, 0.1f, 1.0f, stream));
+  return TD_OK;
+}
+
+// Conditioning of one prompt: context_embedder(prompt_embeds), text_embedder(pooled), RoPE tables.
+// img_ids/txt_ids are device fp32 [n,3]; txt_ids NULL = zeros (thinkdiff/models/flux_prompt.py:119).
+int td_flux_set_condition(td_flux* f, const void* prompt_embeds, int T, const void* pooled, const float* txt_ids,
+                          const float* img_ids, int S_img, void* stream) {
+  TD_CHECK_ARG(f && prompt_embeds && pooled && img_ids, "td_flux_set_condition: null argument");
+  TD_CHECK_ARG(T > 0 && T <= f->max_txt && S_img > 0 && S_img <= f->max_img,
+               "td_flux_set_condition: T=%d / S_img=%d exceed capacity (%d / %d)", T, S_img, f->max_txt, f->max_img);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D;
+  f->T = T; f->S_img = S_img;
+  TD_TRY(gemm(f, s, (const bf16_t*)prompt_embeds, f->cfg.joint_dim, f->ctx_w, f->ctx_b, f->ctx, D, T, D, f->cfg.joint_dim));
+  TD_TRY(gemm(f, s, (const bf16_t*)pooled, f->cfg.pooled_dim, f->p1_w, f->p1_b, f->pmid, D, 1, D, f->cfg.pooled_dim, TD_ACT_SILU));
+  TD_TRY(gemm(f, s, f->pmid, D, f->p2_w, f->p2_b, f->pe, D, 1, D, D));
+  if (txt_ids) TD_CHECK_HIP(hipMemcpyAsync(f->ids, txt_ids, (size_t)T * 12, hipMemcpyDeviceToDevice, s));
+  else TD_CHECK_HIP(hipMemsetAsync(f->ids, 0, (size_t)T * 12, s));
+  TD_CHECK_HIP(hipMemcpyAsync(f->ids + (size_t)T * 3, img_ids, (size_t)S_img * 12, hipMemcpyDeviceToDevice, s));
+  TD_TRY(td_flux_rope_table_launch(f->ids, T + S_img, f->cfg.axes_dims, (double)f->cfg.rope_theta, f->cosT, f->sinT, s));
+  f->cond_set = true;
+  f->n_steps = 0;
+  return TD_OK;
+}
+
+// temb and ALL adaLN modulations for the whole schedule.  t_eff[i] / g_eff are the scalars the
+// sinusoids see (timestep*1000 and guidance*1000 after the caller's dtype handling); host pointers.
+int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, void* stream) {
+  TD_CHECK_ARG(f && t_eff && n > 0 && n <= f->max_steps, "td_flux_set_timesteps: n=%d exceeds capacity %d", n, f ? f->max_steps : 0);
+  TD_CHECK_ARG(f->cond_set, "td_flux_set_timesteps: call td_flux_set_condition first (temb includes the pooled text embedding)");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D;
+  std::vector<float> tv(t_eff, t_eff + n);
+  tv.push_back(g_eff);
+  // pageable H2D copy of <= 260 bytes: synchronous w.r.t. the host buffer, ordered on the stream
+  TD_CHECK_HIP(hipMemcpyAsync(f->tvals, tv.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+  TD_CHECK_HIP(hipStreamSynchronize(s));
+  TD_TRY(td_timestep_sincos_launch(f->tvals, n, f->tproj, s));
+  TD_TRY(gemm(f, s, f->tproj, 256, f->t1_w, f->t1_b, f->tmid, D, n, D, 256, TD_ACT_SILU));
+  TD_TRY(gemm(f, s, f->tmid, D, f->t2_w, f->t2_b, f->te, D, n, D, D));
+  if (f->cfg.guidance_embeds) {
+    TD_TRY(td_timestep_sincos_launch(f->tvals + n, 1, f->gproj, s));
+    TD_TRY(gemm(f, s, f->gproj, 256, f->g1_w, f->g1_b, f->gmid, D, 1, D, 256, TD_ACT_SILU));
+    TD_TRY(gemm(f, s, f->gmid, D, f->g2_w, f->g2_b, f->ge, D, 1, D, D));
+  }
+  TD_TRY(td_temb_combine_silu_launch(f->te, f->cfg.guidance_embeds ? f->ge : nullptr, f->pe, n, D, f->temb, f->st, s));
+  TD_TRY(gemm_big_n(f, s, f->st, D, f->mod_w, f->mod_b, f->mods, f->NMOD, n, f->NMOD, D));
+  f->n_steps = n;
+  return TD_OK;
+}
+
+// One transformer evaluation: velocity[S_img, in_channels] = FluxTransformer2DModel(latents; step).
+int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, void* stream) {
+  TD_CHECK_ARG(f && latents && velocity, "td_flux_forward: null argument");
+  TD_CHECK_ARG(f->cond_set && step >= 0 && step < f->n_steps, "td_flux_forward: step %d outside the %d prepared timesteps", step, f ? f->n_steps : 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D, M = f->M, T = f->T, S = f->T + f->S_img, Si = f->S_img;
+  const int H = f->cfg.num_heads, C = f->cfg.in_channels;
+  const int L = f->cfg.num_layers, Ls = f->cfg.num_single_layers;
+  const bf16_t* mod = f->mods + (size_t)step * f->NMOD;
+  bf16_t* h = f->h;
+  bf16_t* h_img = h + (size_t)T * D;
+  const float scale = 0.08838834764831845f;  // 128^-0.5
+
+  TD_CHECK_HIP(hipMemcpyAsync(h, f->ctx, (size_t)T * D * 2, hipMemcpyDeviceToDevice, s));
+  TD_TRY(gemm(f, s, (const bf16_t*)latents, C, f->x_w, f->x_b, h_img, D, Si, D, C));
+
+  TdNormParams np;
+  np.x = h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = S; np.D = D; np.eps = 1e-6f; np.split = T;
+  TdQkRopeParams rp;
+  rp.qkv = f->qkv; rp.ld = 3 * D; rp.rows = S; rp.Hq = H; rp.Hk = H; rp.q_col = 0; rp.k_col = D;
+  rp.cos = f->cosT; rp.sin = f->sinT; rp.split = T; rp.eps = 1e-6f;
+  TdAttnParams ap;
+  ap.Q = f->qkv; ap.K = f->qkv + D; ap.V = f->qkv + 2 * D; ap.ldq = ap.ldkv = 3 * D;
+  ap.Sq = ap.Skv = S; ap.Hq = ap.Hkv = H; ap.scale = scale; ap.batch = 1;
+
+  for (int i = 0; i < L; ++i) {
+    const DoubleW& w = f->dbl[i];
+    const bf16_t* mi = mod + (size_t)i * 12 * D;  // img: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    const bf16_t* mc = mi + 6 * D;                // ctx: same order
+    np.shiftA = mc; np.scaleA = mc + D; np.shiftB = mi; np.scaleB = mi + D;
+    TD_TRY(td_norm_rows_launch(np, s));
+    TD_TRY(gemm(f, s, f->xn, D, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, 3 * D, T, 3 * D, D));
+    TD_TRY(gemm(f, s, f->xn + (size_t)T * D, D, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, 3 * D, Si, 3 * D, D));
+    rp.wqA = w.norm_added_q; rp.wkA = w.norm_added_k; rp.wqB = w.norm_q; rp.wkB = w.norm_k;
+    TD_TRY(td_qk_norm_rope_launch(rp, s));
+    ap.O = f->attn; ap.ldo = D;
+    TD_TRY(td_attn_launch(ap, s));
+    TD_TRY(gemm(f, s, f->attn, D, w.out_ctx_w, w.out_ctx_b, h, D, T, D, D, TD_ACT_NONE, mc + 2 * D, h, D));
+    TD_TRY(gemm(f, s, f->attn + (size_t)T * D, D, w.out_img_w, w.out_img_b, h_img, D, Si, D, D, TD_ACT_NONE, mi + 2 * D, h_img, D));
+    np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
+    TD_TRY(td_norm_rows_launch(np, s));
+    TD_TRY(gemm(f, s, f->xn, D, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, M, T, M, D, TD_ACT_GELU_TANH));
+    TD_TRY(gemm(f, s, f->xn + (size_t)T * D, D, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, M, Si, M, D, TD_ACT_GELU_TANH));
+    TD_TRY(gemm(f, s, f->mlp, M, w.ff2_ctx_w, w.ff2_ctx_b, h, D, T, D, M, TD_ACT_NONE, mc + 5 * D, h, D));
+    TD_TRY(gemm(f, s, f->mlp + (size_t)T * M, M, w.ff2_img_w, w.ff2_img_b, h_img, D, Si, D, M, TD_ACT_NONE, mi + 5 * D, h_img, D));
+  }
+
+  const bool fused_split = (3 * D) % 256 == 0;
+  for (int i = 0; i < Ls; ++i) {
+    const SingleW& w = f->sgl[i];
+    const bf16_t* ms = mod + (size_t)L * 12 * D + (size_t)i * 3 * D;  // shift, scale, gate
+    np.shiftA = np.shiftB = ms; np.scaleA = np.scaleB = ms + D;
+    TD_TRY(td_norm_rows_launch(np, s));
+    if (fused_split) {
+      TdGemmParams gp;
+      gp.A = f->xn; gp.lda = D; gp.W = w.w1; gp.bias = w.b1; gp.M = S; gp.N = 3 * D + M; gp.K = D;
+      gp.C = f->qkv; gp.ldc = 3 * D; gp.act = TD_ACT_NONE;
+      gp.C2 = f->cat + D; gp.ldc2 = D + M; gp.act2 = TD_ACT_GELU_TANH; gp.n_split = 3 * D;
+      TD_TRY(td_gemm_launch(gp, s));
+    } else {
+      TD_TRY(gemm(f, s, f->xn, D, w.w1, w.b1, f->qkv, 3 * D, S, 3 * D, D));
+      TD_TRY(gemm(f, s, f->xn, D, w.w1 + (size_t)3 * D * D, w.b1 + 3 * D, f->cat + D, D + M, S, M, D, TD_ACT_GELU_TANH));
+    }
+    rp.wqA = rp.wqB = w.norm_q; rp.wkA = rp.wkB = w.norm_k;
+    TD_TRY(td_qk_norm_rope_launch(rp, s));
+    ap.O = f->cat; ap.ldo = D + M;
+    TD_TRY(td_attn_launch(ap, s));
+    TD_TRY(gemm(f, s, f->cat, D + M, w.w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
+  }
+
+  // AdaLayerNormContinuous: chunk order (scale, shift); image rows only
+  const bf16_t* mf = mod + (size_t)L * 12 * D + (size_t)Ls * 3 * D;
+  TdNormParams nf = np;
+  nf.x = h_img; nf.y = f->xn; nf.rows = Si; nf.split = 0;
+  nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
+  TD_TRY(td_norm_rows_launch(nf, s));
+  TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
+  return TD_OK;
+}
+
+// The FluxPipeline.__call__ loop: for i: v = transformer(x, t_i); x = bf16(float(x) + (sigma_{i+1}-sigma_i) float(v)).
+// latents [S_img, in_channels] bf16, updated in place; sigmas: n+1 host floats.
+int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream) {
+  TD_CHECK_ARG(f && latents && sigmas, "td_flux_denoise: null argument");
+  TD_CHECK_ARG(n > 0 && n <= f->n_steps, "td_flux_denoise: n=%d exceeds the %d prepared timesteps", n, f->n_steps);
+  for (int i = 0; i < n; ++i) {
+    TD_TRY(td_flux_forward(f, latents, i, f->vout, stream));
+    TD_TRY(td_euler_step_launch((bf16_t*)latents, f->vout, sigmas[i + 1] - sigmas[i], (long long)f->S_img * f->cfg.in_channels, (hipStream_t)stream));
+  }
+  return TD_OK;
+}
+
+}  // extern "C"

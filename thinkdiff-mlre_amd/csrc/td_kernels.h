@@ -37,3 +37,36 @@ struct TdAttnParams {
 };
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);
+
+struct TdNormParams {
+  const bf16_t* x = nullptr; int ldx = 0;
+  bf16_t* y = nullptr; int ldy = 0;
+  int rows = 0, D = 0;
+  int rms = 0;        // 0: LayerNorm statistics (mean/var), 1: RMSNorm
+  float eps = 1e-6f;
+  const bf16_t* w = nullptr;  // optional affine weight [D]
+  int split = 0;              // rows < split use set A, others set B
+  const bf16_t* shiftA = nullptr; const bf16_t* scaleA = nullptr;
+  const bf16_t* shiftB = nullptr; const bf16_t* scaleB = nullptr;
+};
+int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream);
+
+struct TdQkRopeParams {
+  bf16_t* qkv = nullptr; int ld = 0;   // fused projection rows; modified in place
+  int rows = 0, Hq = 0, Hk = 0;
+  int q_col = 0, k_col = 0;            // first column of the q / k head blocks
+  const float* cos = nullptr; const float* sin = nullptr;  // [rows,128] fp32
+  int split = 0;
+  const bf16_t* wqA = nullptr; const bf16_t* wkA = nullptr;  // rows < split (null: no norm)
+  const bf16_t* wqB = nullptr; const bf16_t* wkB = nullptr;
+  float eps = 1e-6f;
+  int rotate_half = 0;  // 0: interleaved pairs (FLUX), 1: half-split (Qwen2)
+};
+int td_qk_norm_rope_launch(const TdQkRopeParams& p, hipStream_t stream);
+
+int td_flux_rope_table_launch(const float* ids, int S, const int* axes, double theta, float* cosT, float* sinT, hipStream_t stream);
+int td_timestep_sincos_launch(const float* t, int n, bf16_t* out, hipStream_t stream);
+int td_temb_combine_silu_launch(const bf16_t* te, const bf16_t* ge, const bf16_t* pe, int n, int D, bf16_t* temb, bf16_t* silu_out, hipStream_t stream);
+int td_euler_step_launch(bf16_t* x, const bf16_t* v, float dt, long long n, hipStream_t stream);
+int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add, hipStream_t stream);
+int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t stream);

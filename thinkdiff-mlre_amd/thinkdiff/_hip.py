@@ -41,12 +41,33 @@ def _declare(L):
         "td_abi_version": [],
         "td_linear_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp],
         "td_linear_split_bf16": [vp, i64, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp],
+        "td_norm_rows_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp],
+        "td_qk_norm_rope_bf16": [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, vp],
+        "td_flux_rope_table": [vp, i32, vp, ctypes.c_double, vp, vp, vp],
+        "td_timestep_sincos": [vp, i32, vp, vp],
+        "td_euler_step_bf16": [vp, vp, f32, i64, vp],
+        "td_flux_pack_latents": [vp, vp, i32, i32, i32, i32, f32, f32, vp],
+        "td_cls_avgpool2_bf16": [vp, vp, i32, i32, vp],
+        "td_fill_normal_bf16": [vp, i64, ctypes.c_uint64, f32, f32, vp],
+        "td_flux_create": [vp, i32, i32, i32, vp],
+        "td_flux_num_params": [vp],
+        "td_flux_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
+        "td_flux_load_param": [vp, ctypes.c_char_p, vp, i64, vp],
+        "td_flux_init_random": [vp, ctypes.c_uint64, f32, vp],
+        "td_flux_set_condition": [vp, vp, i32, vp, vp, vp, i32, vp],
+        "td_flux_set_timesteps": [vp, vp, i32, f32, vp],
+        "td_flux_forward": [vp, vp, i32, vp, vp],
+        "td_flux_denoise": [vp, vp, vp, i32, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = ctypes.c_int
+    L.td_flux_destroy.argtypes = [vp]
+    L.td_flux_destroy.restype = None
+    L.td_flux_param_elems.argtypes = [vp]
+    L.td_flux_param_elems.restype = ctypes.c_int64
     return sig
 
 
@@ -106,3 +127,82 @@ def attention(q, k, v, out, Hq, Hkv, scale=None, causal=False):
                                   ptr(out), out.stride(1), out.stride(0), B, Sq, Skv, Hq, Hkv, 128,
                                   float(scale), int(causal), stream_ptr()))
     return out
+
+
+class TdFluxConfig(ctypes.Structure):
+    """Mirror of `struct TdFluxConfig` (include/thinkdiff_hip.h)."""
+    _fields_ = [("in_channels", ctypes.c_int), ("num_layers", ctypes.c_int), ("num_single_layers", ctypes.c_int),
+                ("num_heads", ctypes.c_int), ("head_dim", ctypes.c_int), ("joint_dim", ctypes.c_int),
+                ("pooled_dim", ctypes.c_int), ("guidance_embeds", ctypes.c_int), ("mlp_ratio", ctypes.c_int),
+                ("axes_dims", ctypes.c_int * 3), ("rope_theta", ctypes.c_float)]
+
+
+def norm_rows(x, out=None, rms=False, eps=1e-6, w=None, split=0, shiftA=None, scaleA=None, shiftB=None, scaleB=None):
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().td_norm_rows_bf16(ptr(x), _rows(x), ptr(out), _rows(out), rows, D, int(rms), float(eps), ptr(w), split,
+                                  ptr(shiftA), ptr(scaleA), ptr(shiftB), ptr(scaleB), stream_ptr()))
+    return out
+
+
+def qk_norm_rope(qkv, Hq, Hk, q_col, k_col, cos, sin, split=0, wqA=None, wkA=None, wqB=None, wkB=None, eps=1e-6,
+                 rotate_half=False):
+    assert cos.dtype == torch.float32 and cos.shape == (qkv.shape[0], 128) and cos.is_contiguous() and sin.is_contiguous()
+    check(lib().td_qk_norm_rope_bf16(ptr(qkv), _rows(qkv), qkv.shape[0], Hq, Hk, q_col, k_col, ptr(cos), ptr(sin), split,
+                                     ptr(wqA), ptr(wkA), ptr(wqB if wqB is not None else wqA),
+                                     ptr(wkB if wkB is not None else wkA), float(eps), int(rotate_half), stream_ptr()))
+    return qkv
+
+
+def flux_rope_table(ids, axes_dims=(16, 56, 56), theta=10000.0):
+    assert ids.dtype == torch.float32 and ids.is_contiguous() and ids.shape[1] == 3
+    S = ids.shape[0]
+    cos = torch.empty(S, 128, dtype=torch.float32, device=ids.device)
+    sin = torch.empty_like(cos)
+    axes = (ctypes.c_int * 3)(*axes_dims)
+    check(lib().td_flux_rope_table(ptr(ids), S, ctypes.cast(axes, ctypes.c_void_p), float(theta), ptr(cos), ptr(sin), stream_ptr()))
+    return cos, sin
+
+
+def timestep_sincos(t):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    out = torch.empty(t.numel(), 256, dtype=torch.bfloat16, device=t.device)
+    check(lib().td_timestep_sincos(ptr(t), t.numel(), ptr(out), stream_ptr()))
+    return out
+
+
+def euler_step(x, v, dt):
+    assert x.is_contiguous() and v.is_contiguous() and x.dtype == v.dtype == torch.bfloat16
+    check(lib().td_euler_step_bf16(ptr(x), ptr(v), float(dt), x.numel(), stream_ptr()))
+    return x
+
+
+def flux_pack_latents(lat):
+    """[C,H,W] bf16 -> [(H/2)(W/2), 4C]"""
+    C, H, W = lat.shape
+    out = torch.empty((H // 2) * (W // 2), C * 4, dtype=torch.bfloat16, device=lat.device)
+    check(lib().td_flux_pack_latents(ptr(lat.contiguous()), ptr(out), C, H, W, 0, 1.0, 0.0, stream_ptr()))
+    return out
+
+
+def flux_unpack_latents(x, C, H, W, mul=1.0, add=0.0):
+    """[(H/2)(W/2), 4C] bf16 -> [C,H,W] * mul + add"""
+    out = torch.empty(C, H, W, dtype=torch.bfloat16, device=x.device)
+    check(lib().td_flux_pack_latents(ptr(x.contiguous()), ptr(out), C, H, W, 1, float(mul), float(add), stream_ptr()))
+    return out
+
+
+def cls_avgpool2(x):
+    n, C = x.shape
+    G = int(round((n - 1) ** 0.5))
+    assert G * G == n - 1 and x.is_contiguous()
+    out = torch.empty(1 + (G // 2) ** 2, C, dtype=torch.bfloat16, device=x.device)
+    check(lib().td_cls_avgpool2_bf16(ptr(x), ptr(out), G, C, stream_ptr()))
+    return out
+
+
+def fill_normal(t, seed, std=1.0, mean=0.0):
+    assert t.is_contiguous() and t.dtype == torch.bfloat16
+    check(lib().td_fill_normal_bf16(ptr(t), t.numel(), seed, float(std), float(mean), stream_ptr()))
+    return t
