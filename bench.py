@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, ThinkDiff-CLIP -> FLUX.1-dev, 1024x1024, 28 steps (BASELINE.json).
+
+One "step" = one image: the reference driver's `diffusion_pipe(prompt_embeds=[1,193,4096],
+pooled_prompt_embeds=[1,768], height=width=1024, num_inference_steps=28, guidance_scale=3.5)` call
+(scripts/test/test_blip_vision_t5_decoder_flux_text.py:234-242) on synthetic inputs and a seeded
+random-init checkpoint of the full FLUX.1-dev shape (11.9 B params), inputs resident in HBM.
+Every rank generates its own image (the reference's multi-GPU semantics: same prompt list, seed+rank),
+so scaling is weak and there is no data-path collective.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "thinkdiff-mlre_amd"))
+sys.path.insert(0, ROOT)
+
+HEIGHT = WIDTH = 1024
+NUM_STEPS = 28
+T_TXT = 193            # 65 aligner tokens + 128 T5 tokens
+GUIDANCE = 3.5
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def flux_flops_per_forward(s_img: int, s_txt: int) -> float:
+    """SURVEY.md 8(d) algorithmic work of one FluxTransformer2DModel.forward, B=1 (FLUX.1-dev dims)."""
+    D, M = 3072, 12288
+    S = s_img + s_txt
+    per_tok = 4 * D * D + 2 * D * M            # 113.25 M MACs per token per (double-stream) block
+    lin = 2 * s_img * 64 * D + 2 * s_txt * 4096 * D + 19 * 2 * per_tok * S + 38 * 2 * per_tok * S + 2 * s_img * D * 64
+    attn = (19 + 38) * 4 * S * S * D
+    return lin + attn + 2.9e9                  # + modulation / time-MLP GEMVs
+
+
+def cpu_baseline(threads: int):
+    """Times the oracle (oracle/flux_ref.py = the reference's own bf16 torch-CPU arithmetic) on a bounded
+    sample -- one double-stream + one single-stream FLUX.1-dev block -- and extrapolates to one image."""
+    from oracle import flux_ref as R
+    torch.set_num_threads(threads)
+    cfg = R.FluxConfig()
+    D = cfg.inner_dim
+    # calibrate the host so the sample stays ~10-30 s
+    a = torch.randn(1024, D).bfloat16(); w = torch.randn(D, D).bfloat16()
+    torch.nn.functional.linear(a, w)
+    t0 = time.time(); torch.nn.functional.linear(a, w); cal = time.time() - t0
+    tfs = 2 * 1024 * D * D / cal / 1e12
+    s_img = 4096
+    full_blocks_flop = 2 * 2 * (4 * D * D + 2 * D * 4 * D) * (s_img + T_TXT) + 2 * 4 * (s_img + T_TXT) ** 2 * D
+    while s_img > 256 and full_blocks_flop * (s_img + T_TXT) / (4096 + T_TXT) / (tfs * 1e12) > 30.0:
+        s_img //= 2
+    g = torch.Generator().manual_seed(0)
+    shapes = {k: v for k, v in R.param_shapes(cfg).items()
+              if k.startswith("transformer_blocks.0.") or k.startswith("single_transformer_blocks.0.")}
+    sd = {k: (0.02 * torch.randn(v, generator=g)).bfloat16() for k, v in shapes.items()}
+    S = s_img + T_TXT
+    hidden = torch.randn(1, s_img, D, generator=g).bfloat16()
+    enc = torch.randn(1, T_TXT, D, generator=g).bfloat16()
+    temb = torch.randn(1, D, generator=g).bfloat16()
+    side = int(s_img ** 0.5)
+    cos, sin = R.rope_tables(torch.cat([torch.zeros(T_TXT, 3), R.latent_image_ids(side, s_img // side)]), cfg.axes_dims_rope)
+    with torch.no_grad():
+        e2, h2 = R.double_block(sd, cfg, 0, hidden, enc, temb, cos, sin)   # warm-up (page-in, oneDNN primitives)
+        joint = torch.cat([e2, h2], dim=1)
+        reps, t_d, t_s = 0, 0.0, 0.0
+        while t_d + t_s < 12.0 and reps < 64:       # ~10-30 s of CPU work
+            t0 = time.time(); R.double_block(sd, cfg, 0, hidden, enc, temb, cos, sin); t_d += time.time() - t0
+            t0 = time.time(); R.single_block(sd, cfg, 0, joint, temb, cos, sin); t_s += time.time() - t0
+            reps += 1
+        t_d, t_s = t_d / reps, t_s / reps
+    # scale the two block times to the cfg-2 token count by algorithmic FLOPs (exact when s_img == 4096)
+    def blk_flop(si, dbl):
+        s = si + T_TXT
+        return 2 * (4 * D * D + 2 * D * 4 * D) * s + 4 * s * s * D
+    k = blk_flop(4096, True) / blk_flop(s_img, True)
+    sec_per_image = NUM_STEPS * (19 * t_d + 38 * t_s) * k
+    return {
+        "value": 1.0 / sec_per_image, "unit": "images/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle/flux_ref.py (torch CPU bf16, the reference pipeline's arithmetic): 1 double-stream block "
+                   f"({t_d:.2f} s) + 1 single-stream block ({t_s:.2f} s) of FLUX.1-dev at S_img={s_img}, T={T_TXT}, mean of {reps} reps; "
+                   f"extrapolated x(19, 38) blocks x {NUM_STEPS} steps" + ("" if s_img == 4096 else f" x{k:.2f} FLOP ratio to S_img=4096")
+                   + f" = {sec_per_image:.0f} s/image"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="images per rank in the timed region")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="skip the per-launch HIP-event trace (roofline leg)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
+    pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=256, max_steps=32)
+    tr = pipe.transformer
+
+    # synthetic inputs (SURVEY.md 8d cfg 2), seed + rank as the reference drivers do
+    g = torch.Generator().manual_seed(42 + rank)
+    prompt_embeds = (0.1 * torch.randn(1, T_TXT, 4096, generator=g)).bfloat16().cuda()
+    pooled = torch.randn(1, 768, generator=g).bfloat16().cuda()
+    raw = torch.randn(1, 16, HEIGHT // 8, WIDTH // 8, generator=g).bfloat16().cuda()
+    from thinkdiff import _hip
+    packed = _hip.flux_pack_latents(raw[0])[None]
+    torch.cuda.synchronize()
+
+    def one_image():
+        return pipe(prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled, num_images_per_prompt=1,
+                    height=HEIGHT, width=WIDTH, num_inference_steps=NUM_STEPS, guidance_scale=GUIDANCE,
+                    latents=packed.clone(), output_type="vae_input").images
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = one_image()
+    fence()
+    # The per-launch HIP-event trace (roofline leg) brackets every kernel of the LAST timed image on the
+    # launch stream; tracing all K images would cost ~4 % of `value` (two event records per launch).
+    trace = not a.no_trace
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        if trace and i == a.steps - 1:
+            tr.trace_begin(NUM_STEPS * 460 + 64)
+        out = one_image()
+    fence()
+    elapsed = time.perf_counter() - t0
+    cats = tr.trace_end() if trace else None
+    assert bool(torch.isfinite(out.float()).all()), "non-finite latents"
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = world * a.steps / elapsed
+        flops_img = NUM_STEPS * flux_flops_per_forward(4096, T_TXT)
+        res = {
+            "metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE config 2: ThinkDiff-CLIP single image+text, FLUX.1-dev shape (11.9 B params, seeded "
+                             "random init), 1024x1024, 28 Euler steps, T_txt=193 (65 aligner + 128 T5), joint S=4289, "
+                             "guidance 3.5; step = one image per rank from HBM-resident prompt_embeds/pooled/latents to the "
+                             "unpacked, scaled VAE-decoder input (VAE decode itself is SURVEY 8f 'next' row 1, not yet built)"),
+                "images_per_rank_per_step": 1, "parallelism": f"dp{world} (independent images, seed+rank)",
+                "algorithmic_pflop_per_image": flops_img / 1e15,
+            },
+            "whole_step_tflops_per_gpu": flops_img / (elapsed / a.steps) / 1e12,
+        }
+        if cats:
+            gm = cats["gemm_256x256"]
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            res["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                "kernel": "td_gemm_bf16_nt_kernel<8,4>",
+                "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
+                "avg_flops_per_launch": gm["flops"] / max(gm["launches"], 1),
+            }
+            res["roofline"]["sampled"] = "every launch of the kernel in the last image of the timed region (HIP events on the launch stream)"
+            res["kernel_ms_per_image"] = {k: v["ms"] for k, v in cats.items()}
+            at = cats["attention"]
+            res["attention_tflops"] = at["flops"] / (at["ms"] * 1e-3) / 1e12 if at["ms"] > 0 else 0.0
+        if world == 1 and not a.no_cpu_baseline:
+            # the 1-GPU box's CPU share is 16 cores; never oversubscribe past the affinity mask
+            res["cpu_baseline"] = cpu_baseline(min(len(os.sched_getaffinity(0)), 16))
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,11 @@ int td_flux_set_condition(td_flux* f, const void* prompt_embeds, int T, const vo
 int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, void* stream);
 /* velocity[S_img,in_channels] = transformer(latents[S_img,in_channels]; prepared step) */
 int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, void* stream);
+/* Per-launch HIP-event trace of the engine's kernels (events recorded on the launch stream).
+ * categories: 0 main GEMM tile (td_gemm_bf16_nt_kernel<8,4>), 1 other GEMM tiles, 2 attention,
+ * 3 LayerNorm+modulate, 4 QK-RMSNorm+RoPE.  trace_end synchronises and fills 5-element arrays. */
+int td_flux_trace_begin(td_flux* f, int max_launches);
+int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, double* flops);
 /* n Euler steps in place; sigmas: n+1 host floats */
 int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream);
 

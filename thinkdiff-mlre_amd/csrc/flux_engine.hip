@@ -72,6 +72,11 @@ struct td_flux {
   // state
   int T = 0, S_img = 0, n_steps = 0;
   bool cond_set = false;
+  // optional per-launch HIP-event trace (bench.py roofline leg)
+  bool tracing = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct TraceRec { int cat; double flops; };
+  std::vector<TraceRec> trace;
 };
 
 namespace {
@@ -96,12 +101,45 @@ void add_linear(td_flux* f, const std::string& name, bf16_t* w, bf16_t* b, int64
   add_slot(f, name + ".bias", b + row0, out);
 }
 
+// Brackets one launch with HIP events on ITS stream when tracing is on (categories: TD_TRACE_*).
+struct TraceScope {
+  td_flux* f; hipStream_t s; bool on;
+  TraceScope(td_flux* f_, hipStream_t s_, int cat, double flops) : f(f_), s(s_), on(f_->tracing) {
+    if (!on) return;
+    const size_t i = f->trace.size();
+    if (2 * i + 1 >= f->ev_pool.size()) { on = false; return; }
+    f->trace.push_back({cat, flops});
+    (void)hipEventRecord(f->ev_pool[2 * i], s);
+  }
+  ~TraceScope() {
+    if (on) (void)hipEventRecord(f->ev_pool[2 * (f->trace.size() - 1) + 1], s);
+  }
+};
+
+int gemm_p(td_flux* f, hipStream_t s, const TdGemmParams& p) {
+  TraceScope ts(f, s, td_gemm_config_id(p.M, p.N) == 0 ? TD_TRACE_GEMM_MAIN : TD_TRACE_GEMM_OTHER, 2.0 * p.M * p.N * p.K);
+  return td_gemm_launch(p, s);
+}
+
 int gemm(td_flux* f, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* b, bf16_t* C, int ldc,
          int M, int N, int K, int act = TD_ACT_NONE, const bf16_t* gate = nullptr, const bf16_t* res = nullptr, int ldr = 0) {
   TdGemmParams p;
   p.A = A; p.lda = lda; p.W = W; p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
-  return td_gemm_launch(p, s);
+  return gemm_p(f, s, p);
+}
+
+int norm_rows(td_flux* f, hipStream_t s, const TdNormParams& p) {
+  TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
+  return td_norm_rows_launch(p, s);
+}
+int qk_rope(td_flux* f, hipStream_t s, const TdQkRopeParams& p) {
+  TraceScope ts(f, s, TD_TRACE_QKROPE, 0.0);
+  return td_qk_norm_rope_launch(p, s);
+}
+int attn(td_flux* f, hipStream_t s, const TdAttnParams& p) {
+  TraceScope ts(f, s, TD_TRACE_ATTN, 4.0 * p.Sq * (double)p.Skv * p.Hq * 128.0);
+  return td_attn_launch(p, s);
 }
 
 // N may exceed the 4 GiB buffer-descriptor range of W (the fused modulation matrix is 6.5 GB):
@@ -265,6 +303,7 @@ int td_flux_create(const TdFluxConfig* cfg, int max_img_tokens, int max_txt_toke
 
 void td_flux_destroy(td_flux* f) {
   if (!f) return;
+  for (hipEvent_t ev : f->ev_pool) (void)hipEventDestroy(ev);
   (void)hipFree(f->arena);
   (void)hipFree(f->ws);
   delete f;
@@ -411,17 +450,17 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     const bf16_t* mi = mod + (size_t)i * 12 * D;  // img: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const bf16_t* mc = mi + 6 * D;                // ctx: same order
     np.shiftA = mc; np.scaleA = mc + D; np.shiftB = mi; np.scaleB = mi + D;
-    TD_TRY(td_norm_rows_launch(np, s));
+    TD_TRY(norm_rows(f, s, np));
     TD_TRY(gemm(f, s, f->xn, D, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, 3 * D, T, 3 * D, D));
     TD_TRY(gemm(f, s, f->xn + (size_t)T * D, D, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, 3 * D, Si, 3 * D, D));
     rp.wqA = w.norm_added_q; rp.wkA = w.norm_added_k; rp.wqB = w.norm_q; rp.wkB = w.norm_k;
-    TD_TRY(td_qk_norm_rope_launch(rp, s));
+    TD_TRY(qk_rope(f, s, rp));
     ap.O = f->attn; ap.ldo = D;
-    TD_TRY(td_attn_launch(ap, s));
+    TD_TRY(attn(f, s, ap));
     TD_TRY(gemm(f, s, f->attn, D, w.out_ctx_w, w.out_ctx_b, h, D, T, D, D, TD_ACT_NONE, mc + 2 * D, h, D));
     TD_TRY(gemm(f, s, f->attn + (size_t)T * D, D, w.out_img_w, w.out_img_b, h_img, D, Si, D, D, TD_ACT_NONE, mi + 2 * D, h_img, D));
     np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
-    TD_TRY(td_norm_rows_launch(np, s));
+    TD_TRY(norm_rows(f, s, np));
     TD_TRY(gemm(f, s, f->xn, D, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, M, T, M, D, TD_ACT_GELU_TANH));
     TD_TRY(gemm(f, s, f->xn + (size_t)T * D, D, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, M, Si, M, D, TD_ACT_GELU_TANH));
     TD_TRY(gemm(f, s, f->mlp, M, w.ff2_ctx_w, w.ff2_ctx_b, h, D, T, D, M, TD_ACT_NONE, mc + 5 * D, h, D));
@@ -433,21 +472,21 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     const SingleW& w = f->sgl[i];
     const bf16_t* ms = mod + (size_t)L * 12 * D + (size_t)i * 3 * D;  // shift, scale, gate
     np.shiftA = np.shiftB = ms; np.scaleA = np.scaleB = ms + D;
-    TD_TRY(td_norm_rows_launch(np, s));
+    TD_TRY(norm_rows(f, s, np));
     if (fused_split) {
       TdGemmParams gp;
       gp.A = f->xn; gp.lda = D; gp.W = w.w1; gp.bias = w.b1; gp.M = S; gp.N = 3 * D + M; gp.K = D;
       gp.C = f->qkv; gp.ldc = 3 * D; gp.act = TD_ACT_NONE;
       gp.C2 = f->cat + D; gp.ldc2 = D + M; gp.act2 = TD_ACT_GELU_TANH; gp.n_split = 3 * D;
-      TD_TRY(td_gemm_launch(gp, s));
+      TD_TRY(gemm_p(f, s, gp));
     } else {
       TD_TRY(gemm(f, s, f->xn, D, w.w1, w.b1, f->qkv, 3 * D, S, 3 * D, D));
       TD_TRY(gemm(f, s, f->xn, D, w.w1 + (size_t)3 * D * D, w.b1 + 3 * D, f->cat + D, D + M, S, M, D, TD_ACT_GELU_TANH));
     }
     rp.wqA = rp.wqB = w.norm_q; rp.wkA = rp.wkB = w.norm_k;
-    TD_TRY(td_qk_norm_rope_launch(rp, s));
+    TD_TRY(qk_rope(f, s, rp));
     ap.O = f->cat; ap.ldo = D + M;
-    TD_TRY(td_attn_launch(ap, s));
+    TD_TRY(attn(f, s, ap));
     TD_TRY(gemm(f, s, f->cat, D + M, w.w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
   }
 
@@ -456,8 +495,37 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   TdNormParams nf = np;
   nf.x = h_img; nf.y = f->xn; nf.rows = Si; nf.split = 0;
   nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
-  TD_TRY(td_norm_rows_launch(nf, s));
+  TD_TRY(norm_rows(f, s, nf));
   TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
+  return TD_OK;
+}
+
+// Per-launch HIP-event trace.  begin: arm (events are created once); end: synchronise the stream and
+// return, per category, launch count / summed milliseconds / summed algorithmic FLOPs.
+int td_flux_trace_begin(td_flux* f, int max_launches) {
+  TD_CHECK_ARG(f && max_launches > 0, "td_flux_trace_begin: bad arguments");
+  while ((int)f->ev_pool.size() < 2 * max_launches) {
+    hipEvent_t ev;
+    TD_CHECK_HIP(hipEventCreate(&ev));
+    f->ev_pool.push_back(ev);
+  }
+  f->trace.clear();
+  f->trace.reserve(max_launches);
+  f->tracing = true;
+  return TD_OK;
+}
+
+int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, double* flops) {
+  TD_CHECK_ARG(f && counts && ms && flops, "td_flux_trace_end: null argument");
+  f->tracing = false;
+  TD_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  for (int c = 0; c < TD_TRACE_NCAT; ++c) { counts[c] = 0; ms[c] = 0.0; flops[c] = 0.0; }
+  for (size_t i = 0; i < f->trace.size(); ++i) {
+    float t = 0.f;
+    TD_CHECK_HIP(hipEventElapsedTime(&t, f->ev_pool[2 * i], f->ev_pool[2 * i + 1]));
+    const int c = f->trace[i].cat;
+    counts[c] += 1; ms[c] += t; flops[c] += f->trace[i].flops;
+  }
   return TD_OK;
 }
 

@@ -255,6 +255,12 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
 
 }  // namespace
 
+int td_gemm_config_id(int M, int N) {
+  if (N <= 64) return 1;
+  if (M <= 32) return 2;
+  return 0;
+}
+
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "td_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   TD_CHECK_ARG(p.K % BK == 0, "td_gemm: K=%d must be a multiple of %d", p.K, BK);
@@ -266,7 +272,9 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
                "td_gemm: pointers / leading dimensions must be 16-byte aligned");
   if (p.res) TD_CHECK_ARG(p.ldr % 4 == 0, "td_gemm: ldr must be a multiple of 4");
   if (p.C2) TD_CHECK_ARG(p.ldc2 % 8 == 0 && p.n_split % 8 == 0 && p.n_split < p.N, "td_gemm: bad split-output arguments");
-  if (p.N <= 64) return launch_cfg<8, 1>(p, stream);
-  if (p.M <= 32) return launch_cfg<1, 4>(p, stream);
-  return launch_cfg<8, 4>(p, stream);
+  switch (td_gemm_config_id(p.M, p.N)) {
+    case 1: return launch_cfg<8, 1>(p, stream);
+    case 2: return launch_cfg<1, 4>(p, stream);
+    default: return launch_cfg<8, 4>(p, stream);
+  }
 }

@@ -21,6 +21,10 @@ struct TdGemmParams {
 };
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);
+// 0: 256x256 main tile (td_gemm_bf16_nt_kernel<8,4>), 1: 256x64, 2: 32x256
+int td_gemm_config_id(int M, int N);
+
+enum { TD_TRACE_GEMM_MAIN = 0, TD_TRACE_GEMM_OTHER = 1, TD_TRACE_ATTN = 2, TD_TRACE_NORM = 3, TD_TRACE_QKROPE = 4, TD_TRACE_NCAT = 5 };
 
 // q/k/v are read in place from projection outputs: token row s, head h at column h*128.
 struct TdAttnParams {

@@ -58,6 +58,8 @@ def _declare(L):
         "td_flux_set_timesteps": [vp, vp, i32, f32, vp],
         "td_flux_forward": [vp, vp, i32, vp, vp],
         "td_flux_denoise": [vp, vp, vp, i32, vp],
+        "td_flux_trace_begin": [vp, i32],
+        "td_flux_trace_end": [vp, vp, vp, vp, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
     }
     for name, args in sig.items():

@@ -1,0 +1,189 @@
+"""`FluxPipelineRewritePrompt` on the MI355X HIP engine.
+
+Drop-in for reference `thinkdiff/models/flux_prompt.py:16-121` (a `diffusers.FluxPipeline` subclass
+whose `encode_prompt` lets callers inject `prompt_embeds` of any length) together with the inherited
+[ext] diffusers 0.31.0 `FluxPipeline.__call__` the drivers invoke
+(scripts/test/test_blip_vision_t5_decoder_flux_text.py:234-242).  Same names, argument meaning and
+return shapes; the denoise loop itself runs in libthinkdiff_hip.so (`td_flux_*`).
+
+What is host-side here is only scalar schedule arithmetic and argument plumbing.  Text encoders
+(CLIP-L / T5-XXL) and the VAE are optional components (SURVEY.md 8f "next" rows): without a VAE the
+call returns latents (`output_type="latent"`).
+"""
+import math
+from types import SimpleNamespace
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from .. import _hip
+from .flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+
+
+class FlowMatchEulerSchedule:
+    """Scalar part of [ext] FlowMatchEulerDiscreteScheduler with the FLUX.1-dev scheduler_config.json
+    (use_dynamic_shifting, base_shift 0.5, max_shift 1.15, base/max_image_seq_len 256/4096)."""
+    base_image_seq_len, max_image_seq_len, base_shift, max_shift = 256, 4096, 0.5, 1.15
+    num_train_timesteps = 1000
+
+    @classmethod
+    def calculate_shift(cls, image_seq_len: int) -> float:
+        m = (cls.max_shift - cls.base_shift) / (cls.max_image_seq_len - cls.base_image_seq_len)
+        return image_seq_len * m + (cls.base_shift - m * cls.base_image_seq_len)
+
+    @classmethod
+    def sigmas(cls, num_inference_steps: int, image_seq_len: int) -> np.ndarray:
+        s = np.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps)
+        mu = cls.calculate_shift(image_seq_len)
+        s = math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0) ** 1.0)
+        return np.concatenate([s.astype(np.float32), np.zeros(1, dtype=np.float32)])
+
+
+class FluxPipelineRewritePrompt:
+    vae_scale_factor = 16          # [ext] FluxPipeline.__init__ (0.31.0): 2 ** len(vae.block_out_channels)
+    vae_scaling_factor = 0.3611    # [ext] FLUX.1-dev vae/config.json
+    vae_shift_factor = 0.1159
+    default_sample_size = 64
+
+    def __init__(self, scheduler=None, vae=None, text_encoder=None, tokenizer=None, text_encoder_2=None,
+                 tokenizer_2=None, transformer: Optional[FluxTransformer2DModel] = None):
+        self.scheduler = scheduler or FlowMatchEulerSchedule()
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.transformer = transformer
+        self._progress = {}
+
+    # ---- construction --------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, torch_dtype=torch.bfloat16, **kw):
+        """Local directory in diffusers layout (transformer/ required).  Hub ids cannot be fetched here."""
+        import os
+        if not os.path.isdir(pretrained_model_name_or_path):
+            raise FileNotFoundError(
+                f"{pretrained_model_name_or_path!r} is not a local directory; this build loads FLUX weights from "
+                "disk only (or use FluxPipelineRewritePrompt.from_random for synthetic weights)")
+        return cls(transformer=FluxTransformer2DModel.from_pretrained(pretrained_model_name_or_path, **kw))
+
+    @classmethod
+    def from_random(cls, config: Optional[FluxTransformerConfig] = None, seed: int = 0, **kw):
+        """Synthetic FLUX.1-dev-shaped checkpoint created on the device (benchmarks, plumbing tests)."""
+        return cls(transformer=FluxTransformer2DModel(config, **kw).init_random(seed))
+
+    def to(self, *_a, **_k):
+        return self  # the engine lives on the GPU it was created on
+
+    def enable_model_cpu_offload(self, *_a, **_k):
+        return None  # 288 GB of HBM: everything stays resident
+
+    def set_progress_bar_config(self, **kw):
+        self._progress.update(kw)
+
+    @property
+    def _execution_device(self):
+        return self.transformer.device
+
+    # ---- reference flux_prompt.py:37-121 ------------------------------------------------------------------
+    def encode_prompt(self, prompt: Union[str, List[str], None], prompt_2: Union[str, List[str], None] = None,
+                      device=None, num_images_per_prompt: int = 1, prompt_embeds=None, pooled_prompt_embeds=None,
+                      max_sequence_length: int = 512, lora_scale=None):
+        """Pooled (CLIP) and sequence (T5) embeddings are computed independently, each only when the
+        caller did not supply it; text_ids = zeros[T, 3] (no batch dim), T following the embeds."""
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        if pooled_prompt_embeds is None:
+            pooled_prompt_embeds = self._get_clip_prompt_embeds(prompt, device, num_images_per_prompt)
+        if prompt_embeds is None:
+            prompt_2 = prompt_2 or prompt
+            prompt_2 = [prompt_2] if isinstance(prompt_2, str) else prompt_2
+            prompt_embeds = self._get_t5_prompt_embeds(prompt_2, num_images_per_prompt, max_sequence_length, device)
+        dtype = self.transformer.dtype
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3).to(device=device, dtype=dtype)
+        return prompt_embeds, pooled_prompt_embeds, text_ids
+
+    def _get_clip_prompt_embeds(self, prompt, device, num_images_per_prompt):
+        if self.text_encoder is None or self.tokenizer is None:
+            raise _hip.ThinkDiffHipError("encode_prompt: no CLIP text encoder loaded; pass pooled_prompt_embeds")
+        ids = self.tokenizer(prompt, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        out = self.text_encoder(ids.to(device), output_hidden_states=False).pooler_output
+        return out.to(self.transformer.dtype).repeat(1, num_images_per_prompt).view(len(prompt) * num_images_per_prompt, -1)
+
+    def _get_t5_prompt_embeds(self, prompt, num_images_per_prompt, max_sequence_length, device):
+        if self.text_encoder_2 is None or self.tokenizer_2 is None:
+            raise _hip.ThinkDiffHipError("encode_prompt: no T5 text encoder loaded; pass prompt_embeds")
+        ids = self.tokenizer_2(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                               return_tensors="pt").input_ids
+        out = self.text_encoder_2(ids.to(device), output_hidden_states=False)[0].to(self.transformer.dtype)
+        _, T, _ = out.shape
+        return out.repeat(1, num_images_per_prompt, 1).view(len(prompt) * num_images_per_prompt, T, -1)
+
+    # ---- [ext] FluxPipeline helpers -----------------------------------------------------------------------
+    @staticmethod
+    def _prepare_latent_image_ids(h2: int, w2: int, device) -> torch.Tensor:
+        ids = torch.zeros(h2, w2, 3)
+        ids[..., 1] += torch.arange(h2)[:, None]
+        ids[..., 2] += torch.arange(w2)[None, :]
+        return ids.reshape(h2 * w2, 3).to(device)
+
+    def prepare_latents(self, batch: int, height: int, width: int, generator=None, latents=None):
+        """Returns packed latents [B, (h/2)(w/2), 64] bf16 and the latent (h, w).  `latents`, if given, is
+        already packed (as in diffusers)."""
+        c = self.transformer.config.in_channels // 4
+        h = 2 * (int(height) // self.vae_scale_factor)
+        w = 2 * (int(width) // self.vae_scale_factor)
+        dev = self._execution_device
+        if latents is not None:
+            return latents.to(dev, torch.bfloat16).contiguous(), h, w
+        raw = torch.randn((batch, c, h, w), generator=generator, device=dev, dtype=torch.bfloat16)
+        packed = torch.stack([_hip.flux_pack_latents(raw[b]) for b in range(batch)])
+        return packed, h, w
+
+    # ---- the call the drivers make --------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, prompt_2=None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 28, guidance_scale: float = 3.5, num_images_per_prompt: int = 1,
+                 generator=None, latents=None, prompt_embeds=None, pooled_prompt_embeds=None,
+                 output_type: str = "pil", return_dict: bool = True, max_sequence_length: int = 512, **_ignored):
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        prompt_embeds, pooled_prompt_embeds, text_ids = self.encode_prompt(
+            prompt=prompt, prompt_2=prompt_2, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+            num_images_per_prompt=num_images_per_prompt, max_sequence_length=max_sequence_length)
+        tr = self.transformer
+        # [ext] pipeline_flux.py: batch = prompt_embeds.shape[0]; latents for batch * num_images_per_prompt.
+        # The reference's encode_prompt does not tile supplied embeds (flux_prompt.py:83-86), so sample b
+        # is conditioned on prompt b // num_images_per_prompt.
+        B = prompt_embeds.shape[0] * num_images_per_prompt
+        lat, h, w = self.prepare_latents(B, height, width, generator, latents)
+        S_img = lat.shape[1]
+        img_ids = self._prepare_latent_image_ids(h // 2, w // 2, lat.device)
+        sig = self.scheduler.sigmas(num_inference_steps, S_img)
+        t_eff = [effective_scalar(float(s) * self.scheduler.num_train_timesteps, tr.dtype) for s in sig[:-1]]
+        g_eff = float((torch.tensor([guidance_scale], dtype=torch.float32).to(tr.dtype) * 1000).float()) \
+            if tr.config.guidance_embeds else 0.0
+        n_prompts = prompt_embeds.shape[0]
+        outs = []
+        for b in range(B):
+            pb = min(b // num_images_per_prompt, n_prompts - 1)
+            tr.set_condition(prompt_embeds[pb], pooled_prompt_embeds[min(pb, pooled_prompt_embeds.shape[0] - 1)], img_ids, text_ids)
+            tr.set_timesteps(t_eff, g_eff)
+            x = lat[b].contiguous()
+            tr.denoise(x, sig)
+            if output_type == "latent":      # diffusers: packed latents, no unpack
+                outs.append(x)
+            else:                            # _unpack_latents + (z / scaling_factor + shift_factor)
+                outs.append(_hip.flux_unpack_latents(x, tr.config.in_channels // 4, h, w,
+                                                     1.0 / self.vae_scaling_factor, self.vae_shift_factor))
+        z = torch.stack(outs)
+        if output_type in ("latent", "vae_input"):
+            images = z
+        elif self.vae is None:
+            raise _hip.ThinkDiffHipError("no VAE loaded: call with output_type='latent' (packed latents) or "
+                                         "'vae_input' (unpacked, scaled decoder input)")
+        else:
+            images = self.vae.decode(z, output_type=output_type)
+        if not return_dict:
+            return (images,)
+        return SimpleNamespace(images=images)

@@ -156,6 +156,20 @@ class FluxTransformer2DModel:
         _hip.check(self._L.td_flux_denoise(self._h, _hip.ptr(latents), ctypes.cast(arr, ctypes.c_void_p), n, _hip.stream_ptr()))
         return latents
 
+    # ---- per-launch HIP-event trace (bench.py roofline leg) ------------------------------------------
+    TRACE_CATEGORIES = ("gemm_256x256", "gemm_other", "attention", "layernorm_modulate", "qk_rmsnorm_rope")
+
+    def trace_begin(self, max_launches: int):
+        _hip.check(self._L.td_flux_trace_begin(self._h, max_launches))
+
+    def trace_end(self):
+        n = len(self.TRACE_CATEGORIES)
+        counts, ms, fl = (ctypes.c_int64 * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        _hip.check(self._L.td_flux_trace_end(self._h, _hip.stream_ptr(), ctypes.cast(counts, ctypes.c_void_p),
+                                             ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p)))
+        return {c: {"launches": int(counts[i]), "ms": float(ms[i]), "flops": float(fl[i])}
+                for i, c in enumerate(self.TRACE_CATEGORIES)}
+
     # ---- diffusers-style call -------------------------------------------------------------------------
     def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids=None,
                 guidance=None, return_dict: bool = False, **_ignored):
