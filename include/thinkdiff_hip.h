@@ -88,6 +88,18 @@ int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream);
 /* counter-based N(mean,std) fill (synthetic checkpoints for throughput runs). */
 int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float mean, void* stream);
 
+/* ThinkDiff aligner `mm_projector` of type "mlp2x_gelu_t5_norm" (every shipped config):
+ *   y = T5LayerNorm(Linear2(GELU_erf(Linear0(x))))        x:[M,K] -> y:[M,hidden]
+ * Replaces build_vision_projector's nn.Sequential (thinkdiff/models/blip_vision_t5_decoder.py:31-61,
+ * call sites :641 and thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:1113-1116).  State-dict
+ * tensors: w0 = mm_projector.0.weight [hidden,K], b0, w2 = mm_projector.2.weight [hidden,hidden], b2,
+ * norm_w = mm_projector.3.weight [hidden].  workspace: 2*M*hidden bf16.  K % 64 == 0, hidden % 512 == 0.
+ * fp32_norm != 0 reproduces the LVLM path (fp32 norm params under autocast: no bf16 rounding inside
+ * the norm, output rounded once). */
+int td_aligner_mlp2x_bf16(const void* x, int64_t ldx, int M, int K, int hidden, const void* w0, const void* b0,
+                          const void* w2, const void* b2, const void* norm_w, float eps, int fp32_norm,
+                          void* workspace, void* y, int64_t ldy, void* stream);
+
 /* ---- FLUX.1 MMDiT denoise engine ------------------------------------------------------------------
  * Replaces the `diffusion_pipe(prompt_embeds=..., pooled_prompt_embeds=..., height, width,
  * num_inference_steps, guidance_scale)` denoise loop the reference drivers call

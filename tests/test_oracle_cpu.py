@@ -1,0 +1,85 @@
+"""The oracle against the committed golden vectors (tests/golden/, generator: make_golden.py) and against
+the torch / transformers modules the reference instantiates."""
+import os
+
+import pytest
+import torch
+
+from oracle import aligner_ref as A
+from oracle import flux_ref as R
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return torch.load(os.path.join(G, name), weights_only=False)
+
+
+@pytest.mark.parametrize("name,tol", [("aligner_clip_fp32.pt", 1e-5), ("aligner_clip_bf16.pt", 0.0), ("aligner_lvlm7b_bf16.pt", 0.0)])
+def test_aligner_oracle_matches_reference_modules(name, tol):
+    """Golden output came from nn.Sequential(Linear, GELU, Linear, transformers.T5LayerNorm) + F.interpolate."""
+    fx = _load(name)
+    dtype = torch.float32 if "float32" in fx["dtype"] else torch.bfloat16
+    sd = {k: v.to(dtype) for k, v in A.init_weights(fx["mm_hidden"], fx["hidden"], seed=fx["seed"], dtype=torch.float32).items()}
+    g = torch.Generator().manual_seed(fx["seed"] + 1)
+    x = torch.randn(1, fx["tokens"], fx["mm_hidden"], generator=g).to(dtype)
+    y = A.forward_encoder_tail(sd, x) if fx["tokens"] == 257 else A.mm_projector(sd, x)
+    assert y.shape == fx["expected"].shape == (1, 65 if fx["tokens"] == 257 else fx["tokens"], 4096)
+    assert (y.float() - fx["expected"].float()).abs().max() <= tol
+
+
+def test_bilinear_2x_equals_2x2_mean():
+    """F.interpolate(bilinear, align_corners=False) at exactly 2x == 2x2 average pooling."""
+    x = torch.randn(1, 257, 64)
+    a = A.pool_vision_tokens(x)
+    grid = x[:, 1:].reshape(1, 16, 16, 64).permute(0, 3, 1, 2)
+    b = torch.nn.functional.avg_pool2d(grid, 2).permute(0, 2, 3, 1).reshape(1, 64, 64)
+    assert a.shape == (1, 65, 64) and torch.equal(a[:, 0], x[:, 0])
+    assert (a[:, 1:] - b).abs().max() < 1e-6
+
+
+def test_flux_oracle_drift():
+    fx = _load("flux_tiny_oracle.pt")
+    cfg = R.tiny_config(num_layers=fx["layers"], num_single_layers=fx["singles"])
+    sd = R.init_weights(cfg, seed=fx["seed"])
+    g = torch.Generator().manual_seed(fx["seed"] + 1)
+    h2, w2, T = fx["h2"], fx["w2"], fx["T"]
+    lat = torch.randn(1, h2 * w2, 64, generator=g).bfloat16()
+    pe = torch.randn(1, T, cfg.joint_attention_dim, generator=g).bfloat16()
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g).bfloat16()
+    with torch.no_grad():
+        fwd = R.transformer_forward(sd, cfg, lat, pe, pool, torch.tensor([0.5]).bfloat16(),
+                                    R.latent_image_ids(h2, w2).bfloat16(), torch.zeros(T, 3).bfloat16(), torch.tensor([3.5]))
+        den = R.denoise(sd, cfg, lat, pe, pool, h2, w2, 3)
+    # bf16 CPU kernels may differ in summation order across hosts: compare at bf16 resolution
+    assert (fwd.float() - fx["forward"].float()).abs().max() <= 0.03 * fx["forward"].float().abs().max()
+    assert (den.float() - fx["denoise3"].float()).abs().max() <= 0.03 * fx["denoise3"].float().abs().max()
+
+
+def test_flux_oracle_structure():
+    """Properties any correct restatement must have."""
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1)
+    sd = {k: v.float() for k, v in R.init_weights(cfg, seed=5).items()}
+    g = torch.Generator().manual_seed(1)
+    h2 = w2 = 4
+    T = 8
+    lat = torch.randn(1, 16, 64, generator=g)
+    pe = torch.randn(1, T, cfg.joint_attention_dim, generator=g)
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g)
+    ids = R.latent_image_ids(h2, w2)
+    t, gd = torch.tensor([0.3]), torch.tensor([3.5])
+    base = R.transformer_forward(sd, cfg, lat, pe, pool, t, ids, torch.zeros(T, 3), gd)
+    # text ids are all zero => RoPE is the identity on text tokens: permuting text tokens permutes nothing in the image output
+    perm = torch.randperm(T, generator=g)
+    assert (R.transformer_forward(sd, cfg, lat, pe[:, perm], pool, t, ids, torch.zeros(T, 3), gd) - base).abs().max() < 1e-4
+    # AdaLayerNormContinuous chunk order is (scale, shift): swapping the two halves of norm_out.linear changes the output
+    sd2 = dict(sd)
+    w = sd["norm_out.linear.weight"]
+    sd2["norm_out.linear.weight"] = torch.cat([w[w.shape[0] // 2:], w[: w.shape[0] // 2]])
+    assert (R.transformer_forward(sd2, cfg, lat, pe, pool, t, ids, torch.zeros(T, 3), gd) - base).abs().max() > 1e-3
+    # rope tables: [S,128], text rows identity
+    cos, sin = R.rope_tables(torch.cat([torch.zeros(T, 3), ids]), cfg.axes_dims_rope)
+    assert cos.shape == (T + 16, 128) and torch.all(cos[:T] == 1) and torch.all(sin[:T] == 0)
+    # timestep embedding is [cos | sin]
+    e = R.timestep_proj(torch.tensor([0.0]))
+    assert torch.all(e[0, :128] == 1) and torch.all(e[0, 128:] == 0)

@@ -94,4 +94,26 @@ int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream) {
   return td_cls_avgpool2_launch((const bf16_t*)x, (bf16_t*)y, G, C, (hipStream_t)stream);
 }
 
+int td_aligner_mlp2x_bf16(const void* x, int64_t ldx, int M, int K, int hidden, const void* w0, const void* b0,
+                          const void* w2, const void* b2, const void* norm_w, float eps, int fp32_norm,
+                          void* workspace, void* y, int64_t ldy, void* stream) {
+  TD_CHECK_ARG(x && w0 && w2 && norm_w && workspace && y, "td_aligner_mlp2x: null argument");
+  bf16_t* t0 = (bf16_t*)workspace;
+  bf16_t* t1 = t0 + (size_t)M * hidden;
+  TdGemmParams g;
+  g.A = (const bf16_t*)x; g.lda = (int)ldx; g.W = (const bf16_t*)w0; g.bias = (const bf16_t*)b0;
+  g.C = t0; g.ldc = hidden; g.M = M; g.N = hidden; g.K = K; g.act = TD_ACT_GELU_ERF;
+  int rc = td_gemm_launch(g, (hipStream_t)stream);
+  if (rc) return rc;
+  TdGemmParams g2;
+  g2.A = t0; g2.lda = hidden; g2.W = (const bf16_t*)w2; g2.bias = (const bf16_t*)b2;
+  g2.C = t1; g2.ldc = hidden; g2.M = M; g2.N = hidden; g2.K = hidden;
+  rc = td_gemm_launch(g2, (hipStream_t)stream);
+  if (rc) return rc;
+  TdNormParams n;
+  n.x = t1; n.ldx = hidden; n.y = (bf16_t*)y; n.ldy = (int)ldy; n.rows = M; n.D = hidden;
+  n.rms = fp32_norm ? 2 : 1; n.eps = eps; n.w = (const bf16_t*)norm_w;
+  return td_norm_rows_launch(n, (hipStream_t)stream);
+}
+
 }  // extern "C"

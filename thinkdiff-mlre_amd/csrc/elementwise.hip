@@ -65,13 +65,14 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
     float y[8];
+    const bool keep_f32 = p.rms == 2;  // fp32-weight T5LayerNorm under autocast: one rounding at the end
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = rbf(v[c][i] * rstd);
+    for (int i = 0; i < 8; ++i) y[i] = keep_f32 ? v[c][i] * rstd : rbf(v[c][i] * rstd);
     if (p.w) {
       float w[8];
       unpack8(*(const u32x4_t*)(p.w + col), w);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) y[i] = rbf(y[i] * w[i]);
+      for (int i = 0; i < 8; ++i) y[i] = keep_f32 ? y[i] * w[i] : rbf(y[i] * w[i]);
     }
     if (scale) {
       float sc[8], sh[8];

@@ -49,6 +49,7 @@ def _declare(L):
         "td_flux_pack_latents": [vp, vp, i32, i32, i32, i32, f32, f32, vp],
         "td_cls_avgpool2_bf16": [vp, vp, i32, i32, vp],
         "td_fill_normal_bf16": [vp, i64, ctypes.c_uint64, f32, f32, vp],
+        "td_aligner_mlp2x_bf16": [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, f32, i32, vp, vp, i64, vp],
         "td_flux_create": [vp, i32, i32, i32, vp],
         "td_flux_num_params": [vp],
         "td_flux_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
@@ -208,3 +209,14 @@ def fill_normal(t, seed, std=1.0, mean=0.0):
     assert t.is_contiguous() and t.dtype == torch.bfloat16
     check(lib().td_fill_normal_bf16(ptr(t), t.numel(), seed, float(std), float(mean), stream_ptr()))
     return t
+
+
+def aligner_mlp2x(x, w0, b0, w2, b2, norm_w, eps=1e-6, fp32_norm=False):
+    """y = T5LayerNorm(Linear2(GELU(Linear0(x))))  x:[M,K] bf16 -> [M,hidden] bf16"""
+    M, K = x.shape
+    hidden = w0.shape[0]
+    ws = torch.empty(2 * M * hidden, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(M, hidden, dtype=torch.bfloat16, device=x.device)
+    check(lib().td_aligner_mlp2x_bf16(ptr(x), _rows(x), M, K, hidden, ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(norm_w),
+                                      float(eps), int(fp32_norm), ptr(ws), ptr(y), hidden, stream_ptr()))
+    return y
