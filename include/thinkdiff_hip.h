@@ -45,6 +45,17 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
                          void* y0, int64_t ldy0, int act0, void* y1, int64_t ldy1, int act1,
                          int M, int N, int K, int n_split, void* stream);
 
+/* Two Linear problems in ONE launch (same N, K, strides, activation; own rows, weights, bias, gate,
+ * residual): FluxTransformerBlock applies each projection to the image stream and to the text stream
+ * with different weights ([ext] transformer_flux.py FluxTransformerBlock.forward: to_q/add_q_proj,
+ * to_out/to_add_out, ff/ff_context); the 193-row text problem rides in the image problem's grid.
+ * tile_cfg: -1 auto, 0 256x256, 1 256x64, 2 32x256, 3 288x192. */
+int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* bias0, const void* gate0,
+                            const void* res0, void* y0, const void* x1, int M1, const void* w1,
+                            const void* bias1, const void* gate1, const void* res1, void* y1,
+                            int64_t ldx, int64_t ldy, int64_t ldr, int N, int K, int act, int tile_cfg,
+                            void* stream);
+
 /* o[b,s,h*128+d] = softmax(q.k^T * scale (+causal mask)) . v, head_dim 128, fp32 softmax state.
  * q/k/v/o are token-major: row s of batch b at  ptr + b*bstride + s*ld  (elements), head h at
  * column h*128, so the fused QKV projection output is consumed in place.  Hq % Hkv == 0 (GQA).
@@ -140,8 +151,9 @@ int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, vo
 /* velocity[S_img,in_channels] = transformer(latents[S_img,in_channels]; prepared step) */
 int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, void* stream);
 /* Per-launch HIP-event trace of the engine's kernels (events recorded on the launch stream).
- * categories: 0 main GEMM tile (td_gemm_bf16_nt_kernel<8,4>), 1 other GEMM tiles, 2 attention,
- * 3 LayerNorm+modulate, 4 QK-RMSNorm+RoPE.  trace_end synchronises and fills 5-element arrays. */
+ * categories: 0 GEMM 256x256 tile (td_gemm_bf16_nt_kernel<8,4>), 1 small GEMM tiles, 2 attention,
+ * 3 LayerNorm+modulate, 4 QK-RMSNorm+RoPE, 5 GEMM 288x192 tile (<9,3>).  trace_end synchronises and
+ * fills 6-element arrays. */
 int td_flux_trace_begin(td_flux* f, int max_launches);
 int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, double* flops);
 /* n Euler steps in place; sigmas: n+1 host floats */

@@ -112,3 +112,33 @@ def test_linear_rejects_bad_k(hip):
     w = torch.zeros(8, 40, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(hip.ThinkDiffHipError):
         hip.linear(x, w)
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 3])
+@pytest.mark.parametrize("M0,M1,N,K", [(1024, 193, 768, 512), (300, 65, 3072, 256), (4096, 193, 3072, 3072)])
+def test_linear_grouped_two_problems(hip, M0, M1, N, K, cfg):
+    """Image-stream + text-stream projection of a FLUX double block in one launch, every tile config."""
+    g = torch.Generator().manual_seed(M0 + M1 + cfg)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()
+    x0, x1 = mk(M0, K), mk(M1, K)
+    w0, w1 = (mk(N, K).float() * 0.05).bfloat16(), (mk(N, K).float() * 0.05).bfloat16()
+    b0, b1, g0, g1 = mk(N), mk(N), mk(N), mk(N)
+    h0, h1 = mk(M0, N), mk(M1, N)
+    d0, d1 = h0.cuda(), h1.cuda()
+    hip.linear_grouped2(x0.cuda(), w0.cuda(), b0.cuda(), d0, x1.cuda(), w1.cuda(), b1.cuda(), d1,
+                        gate0=g0.cuda(), res0=d0, gate1=g1.cuda(), res1=d1, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    _close(d0, _ref_linear(x0, w0, b0, gate=g0, res=h0))
+    _close(d1, _ref_linear(x1, w1, b1, gate=g1, res=h1))
+
+
+@pytest.mark.parametrize("M,N,K", [(4289, 3072, 1024), (449, 9216, 512), (100, 192, 64), (289, 200, 128)])
+def test_linear_tile_288x192(hip, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.linear_grouped2(x.cuda(), w.cuda(), b.cuda(), y, None, None, None, None, act=1, tile_cfg=3)
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(x, w, b, act=1), 2.0 ** -6)

@@ -42,6 +42,20 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
   return td_gemm_launch(p, (hipStream_t)stream);
 }
 
+int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* bias0, const void* gate0,
+                            const void* res0, void* y0, const void* x1, int M1, const void* w1,
+                            const void* bias1, const void* gate1, const void* res1, void* y1,
+                            int64_t ldx, int64_t ldy, int64_t ldr, int N, int K, int act, int tile_cfg,
+                            void* stream) {
+  TdGemmParams p;
+  p.A = (const bf16_t*)x0; p.W = (const bf16_t*)w0; p.bias = (const bf16_t*)bias0; p.gate = (const bf16_t*)gate0;
+  p.res = (const bf16_t*)res0; p.C = (bf16_t*)y0; p.M = M0;
+  p.g_A = (const bf16_t*)x1; p.g_W = (const bf16_t*)w1; p.g_bias = (const bf16_t*)bias1; p.g_gate = (const bf16_t*)gate1;
+  p.g_res = (const bf16_t*)res1; p.g_C = (bf16_t*)y1; p.g_M = M1;
+  p.lda = (int)ldx; p.ldc = (int)ldy; p.ldr = (int)ldr; p.N = N; p.K = K; p.act = act; p.cfg = tile_cfg;
+  return td_gemm_launch(p, (hipStream_t)stream);
+}
+
 int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void* k, const void* v,
                       int64_t ldkv, int64_t kv_bstride, void* o, int64_t ldo, int64_t o_bstride,
                       int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,

@@ -117,7 +117,8 @@ struct TraceScope {
 };
 
 int gemm_p(td_flux* f, hipStream_t s, const TdGemmParams& p) {
-  TraceScope ts(f, s, td_gemm_config_id(p.M, p.N) == 0 ? TD_TRACE_GEMM_MAIN : TD_TRACE_GEMM_OTHER, 2.0 * p.M * p.N * p.K);
+  const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K);
+  TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * (p.M + p.g_M) * p.N * p.K);
   return td_gemm_launch(p, s);
 }
 
@@ -126,6 +127,17 @@ int gemm(td_flux* f, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, c
   TdGemmParams p;
   p.A = A; p.lda = lda; p.W = W; p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
+  return gemm_p(f, s, p);
+}
+
+// image-stream + text-stream Linear of a double block in one launch (problem 0 = image rows)
+int gemm2(td_flux* f, hipStream_t s, const bf16_t* A0, const bf16_t* W0, const bf16_t* b0, bf16_t* C0, int M0,
+          const bf16_t* A1, const bf16_t* W1, const bf16_t* b1, bf16_t* C1, int M1, int ld_a, int ld_c, int N, int K,
+          int act = TD_ACT_NONE, const bf16_t* gate0 = nullptr, const bf16_t* gate1 = nullptr, bool residual = false) {
+  TdGemmParams p;
+  p.A = A0; p.W = W0; p.bias = b0; p.C = C0; p.M = M0; p.gate = gate0; p.res = residual ? C0 : nullptr;
+  p.g_A = A1; p.g_W = W1; p.g_bias = b1; p.g_C = C1; p.g_M = M1; p.g_gate = gate1; p.g_res = residual ? C1 : nullptr;
+  p.lda = ld_a; p.ldc = ld_c; p.ldr = ld_c; p.N = N; p.K = K; p.act = act;
   return gemm_p(f, s, p);
 }
 
@@ -451,20 +463,21 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     const bf16_t* mc = mi + 6 * D;                // ctx: same order
     np.shiftA = mc; np.scaleA = mc + D; np.shiftB = mi; np.scaleB = mi + D;
     TD_TRY(norm_rows(f, s, np));
-    TD_TRY(gemm(f, s, f->xn, D, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, 3 * D, T, 3 * D, D));
-    TD_TRY(gemm(f, s, f->xn + (size_t)T * D, D, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, 3 * D, Si, 3 * D, D));
+    bf16_t* xn_img = f->xn + (size_t)T * D;
+    TD_TRY(gemm2(f, s, xn_img, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
+                 f->xn, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
     rp.wqA = w.norm_added_q; rp.wkA = w.norm_added_k; rp.wqB = w.norm_q; rp.wkB = w.norm_k;
     TD_TRY(qk_rope(f, s, rp));
     ap.O = f->attn; ap.ldo = D;
     TD_TRY(attn(f, s, ap));
-    TD_TRY(gemm(f, s, f->attn, D, w.out_ctx_w, w.out_ctx_b, h, D, T, D, D, TD_ACT_NONE, mc + 2 * D, h, D));
-    TD_TRY(gemm(f, s, f->attn + (size_t)T * D, D, w.out_img_w, w.out_img_b, h_img, D, Si, D, D, TD_ACT_NONE, mi + 2 * D, h_img, D));
+    TD_TRY(gemm2(f, s, f->attn + (size_t)T * D, w.out_img_w, w.out_img_b, h_img, Si,
+                 f->attn, w.out_ctx_w, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
     np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
     TD_TRY(norm_rows(f, s, np));
-    TD_TRY(gemm(f, s, f->xn, D, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, M, T, M, D, TD_ACT_GELU_TANH));
-    TD_TRY(gemm(f, s, f->xn + (size_t)T * D, D, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, M, Si, M, D, TD_ACT_GELU_TANH));
-    TD_TRY(gemm(f, s, f->mlp, M, w.ff2_ctx_w, w.ff2_ctx_b, h, D, T, D, M, TD_ACT_NONE, mc + 5 * D, h, D));
-    TD_TRY(gemm(f, s, f->mlp + (size_t)T * M, M, w.ff2_img_w, w.ff2_img_b, h_img, D, Si, D, M, TD_ACT_NONE, mi + 5 * D, h_img, D));
+    TD_TRY(gemm2(f, s, xn_img, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
+                 f->xn, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
+    TD_TRY(gemm2(f, s, f->mlp + (size_t)T * M, w.ff2_img_w, w.ff2_img_b, h_img, Si,
+                 f->mlp, w.ff2_ctx_w, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
   }
 
   const bool fused_split = (3 * D) % 256 == 0;

@@ -36,18 +36,23 @@ __device__ __forceinline__ float apply_act(float x) {
 // Lane owns NV = 4*WN contiguous output columns [nbeg, nbeg+NV) of rows mbeg + 16*i.
 // Rounding points follow the reference's bf16 torch pipeline: Linear output, activation,
 // gate multiply and residual add each round to bf16.
+// the problem a block works on (grouped launches carry two; see TdGemmParams)
+struct ProbView {
+  const bf16_t* bias; const bf16_t* gate; const bf16_t* res; bf16_t* C; int M;
+};
+
 template <int WM, int WN, int ACT>
-__device__ __forceinline__ void epilogue(const TdGemmParams& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second) {
+__device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second) {
   constexpr int NV = 4 * WN;
-  bf16_t* Cout = second ? p.C2 : p.C;
-  const int ldo = second ? p.ldc2 : p.ldc;
-  const int ncol = second ? nbeg - p.n_split : nbeg;
+  bf16_t* Cout = second ? pp.C2 : p.C;
+  const int ldo = second ? pp.ldc2 : pp.ldc;
+  const int ncol = second ? nbeg - pp.n_split : nbeg;
   const bool use_gate = p.gate != nullptr, use_res = p.res != nullptr;
 
   float bias[NV], gate[NV];
 #pragma unroll
   for (int c = 0; c < NV; c += 4) {
-    const bool inr = nbeg + c + 4 <= p.N;
+    const bool inr = nbeg + c + 4 <= pp.N;
     u32x2_t b = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
     if (p.bias && inr) b = *(const u32x2_t*)(p.bias + nbeg + c);
     if (use_gate && inr) g = *(const u32x2_t*)(p.gate + nbeg + c);
@@ -72,10 +77,10 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& p, f32x4_t (&acc)[W
       v[c] = y;
     }
     if (use_res && mok) {
-      const bf16_t* rp = p.res + (size_t)m * p.ldr + nbeg;
+      const bf16_t* rp = p.res + (size_t)m * pp.ldr + nbeg;
 #pragma unroll
       for (int c = 0; c < NV; c += 4) {
-        if (nbeg + c + 4 <= p.N) {
+        if (nbeg + c + 4 <= pp.N) {
           const u32x2_t rv = *(const u32x2_t*)(rp + c);
           v[c] += bf_lo(rv[0]); v[c + 1] += bf_hi(rv[0]); v[c + 2] += bf_lo(rv[1]); v[c + 3] += bf_hi(rv[1]);
         }
@@ -88,14 +93,14 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& p, f32x4_t (&acc)[W
         u32x4_t o;
         o[0] = pack_bf2(v[c], v[c + 1]); o[1] = pack_bf2(v[c + 2], v[c + 3]);
         o[2] = pack_bf2(v[c + 4], v[c + 5]); o[3] = pack_bf2(v[c + 6], v[c + 7]);
-        if (mok && nbeg + c + 8 <= p.N) *(u32x4_t*)(cp + c) = o;
+        if (mok && nbeg + c + 8 <= pp.N) *(u32x4_t*)(cp + c) = o;
       }
     } else {
 #pragma unroll
       for (int c = 0; c < NV; c += 4) {
         u32x2_t o;
         o[0] = pack_bf2(v[c], v[c + 1]); o[1] = pack_bf2(v[c + 2], v[c + 3]);
-        if (mok && nbeg + c + 4 <= p.N) *(u32x2_t*)(cp + c) = o;
+        if (mok && nbeg + c + 4 <= pp.N) *(u32x2_t*)(cp + c) = o;
       }
     }
   }
@@ -103,7 +108,7 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& p, f32x4_t (&acc)[W
 
 }  // namespace
 
-template <int WM, int WN>
+template <int WM, int WN, int VARIANT = 1>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   constexpr int BM = 32 * WM, BN = 64 * WN;
@@ -134,50 +139,59 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     tm = first_m + in_g % gsize;
     tn = in_g / gsize;
   }
+  // grouped launch: m-tiles [0, tiles_m0) belong to problem 0, the rest to problem 1 (same N, K, strides)
+  const bool second_prob = tm >= p.tiles_m0;
+  if (second_prob) tm -= p.tiles_m0;
+  const bf16_t* Aptr = second_prob ? p.g_A : p.A;
+  const bf16_t* Wptr = second_prob ? p.g_W : p.W;
+  ProbView pv;
+  pv.bias = second_prob ? p.g_bias : p.bias;
+  pv.gate = second_prob ? p.g_gate : p.gate;
+  pv.res = second_prob ? p.g_res : p.res;
+  pv.C = second_prob ? p.g_C : p.C;
+  pv.M = second_prob ? p.g_M : p.M;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
-  const unsigned bytesA = (unsigned)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const unsigned bytesA = (unsigned)(((long long)(pv.M - 1) * p.lda + p.K) * 2);
   const unsigned bytesW = (unsigned)((long long)p.N * p.K * 2);
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytesA, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, bytesW, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Aptr, 0, bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wptr, 0, bytesW, 0x00020000);
 
   // ---- per-lane staging source offsets ------------------------------------------------------
   const int srow = lane >> 3;                         // row inside the 8-row group
   const int schunk = ((lane & 7) ^ srow) << 4;        // swizzled 16-B source chunk
-  unsigned voffA[SA], voffW[SW];
+  // NS = SA + SW staging instructions per wave per k-tile; instruction s < SA moves an 8-row group of the
+  // A tile, the rest of the W tile.  A wave whose group index falls past the tile (tile rows not a
+  // multiple of 64) re-stages another wave's group instead: identical bytes, and no divergent skip, so the
+  // instructions can be spread through the MFMA stream of the main loop.
+  constexpr int NS = SA + SW;
+  unsigned voffS[NS];
+  int ldsS[NS];
 #pragma unroll
   for (int s = 0; s < SA; ++s) {
-    const int g = wid + 8 * s;
+    int g = wid + 8 * s;
+    if (GA % 8 != 0 && g >= GA) g %= GA;
     const int row = m0 + g * 8 + srow;
-    voffA[s] = (unsigned)row * (unsigned)p.lda * 2u + schunk;
+    voffS[s] = (unsigned)row * (unsigned)p.lda * 2u + schunk;
+    ldsS[s] = g * 1024;
   }
 #pragma unroll
   for (int s = 0; s < SW; ++s) {
-    const int g = wid + 8 * s;
+    int g = wid + 8 * s;
+    if (GW % 8 != 0 && g >= GW) g %= GW;
     const int rho = g * 8 + srow;                     // LDS row of the block's W slab
     const int wcol = rho / (16 * WN);
     const int rem = rho - wcol * (16 * WN);
     const int j = rem >> 4, i16 = rem & 15;
     const int n = n0 + wcol * (16 * WN) + (i16 >> 2) * NV + j * 4 + (i16 & 3);
-    voffW[s] = (unsigned)n * (unsigned)p.K * 2u + schunk;
+    voffS[SA + s] = (unsigned)n * (unsigned)p.K * 2u + schunk;
+    ldsS[SA + s] = A_BYTES + g * 1024;
   }
-
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE_BYTES;
-    const int soff = kt * (BK * 2);
-#pragma unroll
-    for (int s = 0; s < SA; ++s) {
-      const int g = wid + 8 * s;
-      if (GA % 8 == 0 || g < GA)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)(base + g * 1024), 16, voffA[s], soff, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
-      const int g = wid + 8 * s;
-      if (GW % 8 == 0 || g < GW)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (TD_LDS void*)(base + A_BYTES + g * 1024), 16, voffW[s], soff, 0, 0);
-    }
+  auto stage_one = [&](int s, int buf, int kt) {
+    char* dst = smem + buf * STAGE_BYTES + ldsS[s];
+    if (s < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)dst, 16, voffS[s], kt * (BK * 2), 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (TD_LDS void*)dst, 16, voffS[s], kt * (BK * 2), 0, 0);
   };
 
   // ---- fragment read offsets ------------------------------------------------------------------
@@ -193,25 +207,105 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nt = p.K / BK;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) stage_one(s, 0, 0);
+  if constexpr (VARIANT == 0) {
+    // baseline structure kept for in-process A/B runs: stage the next tile up front, then all fragment
+    // reads of a k-step followed by its MFMAs (compiler-scheduled)
+    for (int t = 0; t < nt; ++t) {
+      __syncthreads();
+      if (t + 1 < nt) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) stage_one(s, (t + 1) & 1, t + 1);
+      }
+      const char* base = smem + (t & 1) * STAGE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int fo = foff0 ^ (ks << 6);
+        bf16x8_t wf[WN], af[WM];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(base + woff + j * 16 * ROW_BYTES + fo);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8_t*)(base + aoff + i * 16 * ROW_BYTES + fo);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+      }
+    }
+  } else {
+  // Main loop, one barrier per k-tile.  Inside a tile every instruction kind is spread through the MFMA
+  // stream (pinned with sched_group_barrier, hipcc otherwise clusters them):
+  //  * the NS LDS-DMA instructions of tile t+1 ride on the first m-tiles (their ~60-cycle issue cost hides
+  //    behind MFMAs instead of fronting the tile while the matrix pipe idles);
+  //  * the WN W-fragments of a k-step stay resident, A-fragments are read one m-tile ahead of the MFMAs
+  //    that consume them, the next k-step's W-fragments behind the last m-tiles.
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // s_waitcnt vmcnt(0) + barrier: tile t landed, buffer (t+1)&1 free
-    if (t + 1 < nt) stage((t + 1) & 1, t + 1);
     const char* base = smem + (t & 1) * STAGE_BYTES;
+    const char* wb = base + woff;
+    const char* ab = base + aoff;
+    // the tile after the last is a harmless re-load of the last one (keeps the loop body branch-free)
+    const int kt_next = min(t + 1, nt - 1);
+    const int buf_next = (t + 1) & 1;
+    bf16x8_t wf[2][WN], af[2];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) wf[0][j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + foff0);
+    af[0] = *(const bf16x8_t*)(ab + foff0);
+    __builtin_amdgcn_sched_group_barrier(0x100, WN + 1, 0);  // the k-step-0 fragments first
+    constexpr int MASK_VMEM = 0x010, MASK_DS_READ = 0x100, MASK_MFMA = 0x008;
+    constexpr int NIT = 2 * WM;                       // (k-step, m-tile) iterations per tile
+    constexpr int S_PER_IT = (NS + NIT - 1) / NIT;    // staging instructions per iteration
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int fo = foff0 ^ (ks << 6);
-      bf16x8_t wf[WN], af[WM];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(base + woff + j * 16 * ROW_BYTES + fo);
+      for (int i = 0; i < WM; ++i) {
+        const int it = ks * WM + i;
+        const int cur = it & 1;
+        int nst = 0;
 #pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8_t*)(base + aoff + i * 16 * ROW_BYTES + fo);
+        for (int q = 0; q < S_PER_IT; ++q) {
+          const int s = it * S_PER_IT + q;
+          if (s < NS) { stage_one(s, buf_next, kt_next); ++nst; }
+        }
+        // prefetch the next A fragment (next m-tile, or m-tile 0 of the next k-step)
+        if (i + 1 < WM) af[cur ^ 1] = *(const bf16x8_t*)(ab + (i + 1) * 16 * ROW_BYTES + fo);
+        else if (ks == 0) af[cur ^ 1] = *(const bf16x8_t*)(ab + (fo ^ 64));
+        // prefetch the next k-step's W fragments behind the last m-tiles (fragment j rides on m-tile WM-1-j%WM)
+        int nwf = 0;
+        if (ks == 0) {
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+          for (int j = 0; j < WN; ++j)
+            if (WM - 1 - (j % WM) == i) {
+              wf[1][j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + (fo ^ 64));
+              ++nwf;
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[cur], acc[j][i], 0, 0, 0);
+        const int nreads = ((i + 1 < WM || ks == 0) ? 1 : 0) + nwf;
+        switch (nst) {  // the builtin wants literal counts
+          case 1: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 1, 0); break;
+          case 2: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 2, 0); break;
+          case 3: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 3, 0); break;
+          default: break;
+        }
+        switch (nreads) {
+          case 1: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 1, 0); break;
+          case 2: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 2, 0); break;
+          case 3: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 3, 0); break;
+          case 4: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 4, 0); break;
+          case 5: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 5, 0); break;
+          default: break;
+        }
+        __builtin_amdgcn_sched_group_barrier(MASK_MFMA, WN, 0);
+      }
     }
+  }
+
   }
 
   // ---- epilogue: lane owns NV contiguous columns of row (lane&15) of each m-tile -------------
@@ -223,42 +317,49 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   // one instantiation per activation keeps every acc[][] index static (runtime-indexed
   // accumulators would be demoted to scratch)
   switch (act) {
-    case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH>(p, acc, mbeg, nbeg, second); break;
-    case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF>(p, acc, mbeg, nbeg, second); break;
-    case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU>(p, acc, mbeg, nbeg, second); break;
-    default: epilogue<WM, WN, TD_ACT_NONE>(p, acc, mbeg, nbeg, second); break;
+    case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH>(p, pv, acc, mbeg, nbeg, second); break;
+    case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF>(p, pv, acc, mbeg, nbeg, second); break;
+    case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU>(p, pv, acc, mbeg, nbeg, second); break;
+    default: epilogue<WM, WN, TD_ACT_NONE>(p, pv, acc, mbeg, nbeg, second); break;
   }
 #endif
 }
 
 namespace {
 
-template <int WM, int WN>
+template <int WM, int WN, int VARIANT = 1>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
   TdGemmParams p = p0;
-  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_m0 = (p.M + BM - 1) / BM;
+  p.tiles_m = p.tiles_m0 + (p.g_M > 0 ? (p.g_M + BM - 1) / BM : 0);
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   static bool attr_set = false;
   if (!attr_set) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN>,
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, VARIANT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, VARIANT>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace
 
-int td_gemm_config_id(int M, int N) {
+// Tile choice.  0: 256x256, 1: 256x64, 2: 32x256, 3: 288x192.  Measured on MI355X (in-process A/B,
+// tools/bench_ops.py gemmcfg): 256x256 wins whenever the grid spans several rounds of the 256 CUs; the
+// 288x192 tile wins where 256x256 leaves a single ragged round (N = 3072 at M = 4289: 204 tiles, but 240
+// tiles of the smaller shape) and K is long enough to amortise its prologue.
+int td_gemm_config_id(int M, int N, int K) {
   if (N <= 64) return 1;
   if (M <= 32) return 2;
-  return 0;
+  const long long t0 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const long long t3 = (long long)((M + 287) / 288) * ((N + 191) / 192);
+  return (t0 < 230 && t3 <= 256 && t3 > t0 && K >= 6144) ? 3 : 0;
 }
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
@@ -272,9 +373,17 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
                "td_gemm: pointers / leading dimensions must be 16-byte aligned");
   if (p.res) TD_CHECK_ARG(p.ldr % 4 == 0, "td_gemm: ldr must be a multiple of 4");
   if (p.C2) TD_CHECK_ARG(p.ldc2 % 8 == 0 && p.n_split % 8 == 0 && p.n_split < p.N, "td_gemm: bad split-output arguments");
-  switch (td_gemm_config_id(p.M, p.N)) {
+  if (p.g_M > 0) {
+    TD_CHECK_ARG(p.g_A && p.g_W && p.g_C && !p.C2, "td_gemm: grouped launch needs A/W/C of the second problem and no split output");
+    TD_CHECK_ARG(((uintptr_t)p.g_A | (uintptr_t)p.g_W | (uintptr_t)p.g_C) % 16 == 0, "td_gemm: grouped pointers must be 16-byte aligned");
+  }
+  const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K);
+  switch (cfg) {
     case 1: return launch_cfg<8, 1>(p, stream);
     case 2: return launch_cfg<1, 4>(p, stream);
+    case 3: return launch_cfg<9, 3>(p, stream);
+    case 10: return launch_cfg<8, 4, 0>(p, stream);   // baseline loop structure, A/B only
+    case 13: return launch_cfg<9, 3, 0>(p, stream);
     default: return launch_cfg<8, 4>(p, stream);
   }
 }

@@ -17,14 +17,20 @@ struct TdGemmParams {
   int lda = 0, ldc = 0, ldr = 0, ldc2 = 0;
   int n_split = 0;
   int act = TD_ACT_NONE, act2 = TD_ACT_NONE;
-  int tiles_m = 0, tiles_n = 0;  // filled by the launcher
+  // optional second problem of a grouped launch (same N, K, lda, ldc, ldr, act; own rows and weights):
+  // the double-stream blocks run their text-token GEMM (M = 193) inside the image-token launch
+  const bf16_t* g_A = nullptr; const bf16_t* g_W = nullptr; const bf16_t* g_bias = nullptr;
+  const bf16_t* g_gate = nullptr; const bf16_t* g_res = nullptr; bf16_t* g_C = nullptr;
+  int g_M = 0;
+  int cfg = -1;                  // tile config override (-1: auto), see td_gemm_config_id
+  int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
 };
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);
-// 0: 256x256 main tile (td_gemm_bf16_nt_kernel<8,4>), 1: 256x64, 2: 32x256
-int td_gemm_config_id(int M, int N);
+// 0: 256x256 (td_gemm_bf16_nt_kernel<8,4>), 1: 256x64, 2: 32x256, 3: 288x192 (<9,3>)
+int td_gemm_config_id(int M, int N, int K);
 
-enum { TD_TRACE_GEMM_MAIN = 0, TD_TRACE_GEMM_OTHER = 1, TD_TRACE_ATTN = 2, TD_TRACE_NORM = 3, TD_TRACE_QKROPE = 4, TD_TRACE_NCAT = 5 };
+enum { TD_TRACE_GEMM_MAIN = 0, TD_TRACE_GEMM_OTHER = 1, TD_TRACE_ATTN = 2, TD_TRACE_NORM = 3, TD_TRACE_QKROPE = 4, TD_TRACE_GEMM_288 = 5, TD_TRACE_NCAT = 6 };
 
 // q/k/v are read in place from projection outputs: token row s, head h at column h*128.
 struct TdAttnParams {

@@ -41,6 +41,7 @@ def _declare(L):
         "td_abi_version": [],
         "td_linear_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp],
         "td_linear_split_bf16": [vp, i64, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp],
+        "td_linear_grouped2_bf16": [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, vp],
         "td_norm_rows_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp],
         "td_qk_norm_rope_bf16": [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, vp],
         "td_flux_rope_table": [vp, i32, vp, ctypes.c_double, vp, vp, vp],
@@ -220,3 +221,15 @@ def aligner_mlp2x(x, w0, b0, w2, b2, norm_w, eps=1e-6, fp32_norm=False):
     check(lib().td_aligner_mlp2x_bf16(ptr(x), _rows(x), M, K, hidden, ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(norm_w),
                                       float(eps), int(fp32_norm), ptr(ws), ptr(y), hidden, stream_ptr()))
     return y
+
+
+def linear_grouped2(x0, w0, b0, y0, x1, w1, b1, y1, act=ACT_NONE, gate0=None, res0=None, gate1=None, res1=None, tile_cfg=-1):
+    """Two Linear problems (same N, K, row strides) in one launch; x1 may be None (M1 = 0)."""
+    M0, K = x0.shape
+    N = w0.shape[0]
+    M1 = 0 if x1 is None else x1.shape[0]
+    ldr = _rows(res0) if res0 is not None else 0
+    check(lib().td_linear_grouped2_bf16(ptr(x0), M0, ptr(w0), ptr(b0), ptr(gate0), ptr(res0), ptr(y0),
+                                        ptr(x1), M1, ptr(w1), ptr(b1), ptr(gate1), ptr(res1), ptr(y1),
+                                        _rows(x0), _rows(y0), ldr, N, K, act, tile_cfg, stream_ptr()))
+    return y0, y1

@@ -157,7 +157,7 @@ class FluxTransformer2DModel:
         return latents
 
     # ---- per-launch HIP-event trace (bench.py roofline leg) ------------------------------------------
-    TRACE_CATEGORIES = ("gemm_256x256", "gemm_other", "attention", "layernorm_modulate", "qk_rmsnorm_rope")
+    TRACE_CATEGORIES = ("gemm_256x256", "gemm_other", "attention", "layernorm_modulate", "qk_rmsnorm_rope", "gemm_288x192")
 
     def trace_begin(self, max_launches: int):
         _hip.check(self._L.td_flux_trace_begin(self._h, max_launches))

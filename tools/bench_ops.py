@@ -40,6 +40,28 @@ def bench_gemm():
         print(f"gemm M={M:5d} N={N:5d} K={K:5d}: {ms:8.3f} ms  {tf:7.1f} TF/s   (hipBLASLt via torch: {ref_ms:8.3f} ms {2.0*M*N*K/ref_ms/1e9:7.1f} TF/s)", flush=True)
 
 
+def bench_gemmcfg():
+    """256x256 vs 288x192 tiles on the FLUX shapes (grouped = image + 193 text rows in one launch)."""
+    shapes = [(4096, 193, 9216, 3072), (4096, 193, 3072, 3072), (4096, 193, 12288, 3072), (4096, 193, 3072, 12288),
+              (4289, 0, 21504, 3072), (4289, 0, 3072, 15360)]
+    for M0, M1, N, K in shapes:
+        x0 = torch.randn(M0, K, device="cuda").bfloat16(); w0 = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+        b0 = torch.randn(N, device="cuda").bfloat16(); y0 = torch.empty(M0, N, device="cuda", dtype=torch.bfloat16)
+        if M1:
+            x1 = torch.randn(M1, K, device="cuda").bfloat16(); w1 = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+            y1 = torch.empty(M1, N, device="cuda", dtype=torch.bfloat16)
+        else:
+            x1 = w1 = y1 = None
+        fl = 2.0 * (M0 + M1) * N * K
+        cfgs = (0, 10, 3, 13)
+        best = {c: 1e9 for c in cfgs}
+        for rnd in range(5):   # interleaved rounds in one process (guide rule 24)
+            for cfg in cfgs:
+                ms = timeit(lambda: _hip.linear_grouped2(x0, w0, b0, y0, x1, w1, b0 if M1 else None, y1, tile_cfg=cfg), iters=10, warmup=2)
+                best[cfg] = min(best[cfg], ms)
+        print(f"M={M0}+{M1} N={N} K={K}:  " + "   ".join(f"cfg{c}: {best[c]:7.3f} ms {fl/best[c]/1e9:7.1f} TF/s" for c in cfgs), flush=True)
+
+
 def bench_attn():
     for S, H in [(4289, 24), (4224, 24), (4096, 24), (8192, 24)]:
         qkv = torch.randn(1, S, 3 * H * 128, device="cuda").bfloat16()
