@@ -114,7 +114,7 @@ def test_linear_rejects_bad_k(hip):
         hip.linear(x, w)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 3])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 10, 33])
 @pytest.mark.parametrize("M0,M1,N,K", [(1024, 193, 768, 512), (300, 65, 3072, 256), (4096, 193, 3072, 3072)])
 def test_linear_grouped_two_problems(hip, M0, M1, N, K, cfg):
     """Image-stream + text-stream projection of a FLUX double block in one launch, every tile config."""

@@ -108,11 +108,11 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
 
 }  // namespace
 
-template <int WM, int WN, int VARIANT = 1>
+template <int WM, int WN, int VARIANT = 2>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   constexpr int BM = 32 * WM, BN = 64 * WN;
-  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
   constexpr int GA = BM / 8, GW = BN / 8;           // 8-row staging groups per tile
   constexpr int SA = (GA + 7) / 8, SW = (GW + 7) / 8;  // staging instructions per wave
   constexpr int NV = 4 * WN;                          // contiguous output columns per lane
@@ -186,19 +186,22 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     const int j = rem >> 4, i16 = rem & 15;
     const int n = n0 + wcol * (16 * WN) + (i16 >> 2) * NV + j * 4 + (i16 & 3);
     voffS[SA + s] = (unsigned)n * (unsigned)p.K * 2u + schunk;
-    ldsS[SA + s] = A_BYTES + g * 1024;
+    ldsS[SA + s] = g * 1024;
   }
-  auto stage_one = [&](int s, int buf, int kt) {
-    char* dst = smem + buf * STAGE_BYTES + ldsS[s];
-    if (s < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)dst, 16, voffS[s], kt * (BK * 2), 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (TD_LDS void*)dst, 16, voffS[s], kt * (BK * 2), 0, 0);
+  // LDS: [A buf 0 | A buf 1 | W buf 0 | W buf 1 | W buf 2]; the third W buffer exists for VARIANT 2 only
+  constexpr int W_REGION = 2 * A_BYTES;
+  auto stage_one = [&](int s, int abuf, int wbuf, int kt) {
+    if (s < SA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)(smem + abuf * A_BYTES + ldsS[s]), 16, voffS[s], kt * (BK * 2), 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (TD_LDS void*)(smem + W_REGION + wbuf * W_BYTES + ldsS[s]), 16, voffS[s], kt * (BK * 2), 0, 0);
   };
 
   // ---- fragment read offsets ------------------------------------------------------------------
   const int frow = lane & 15;
   const int foff0 = frow * ROW_BYTES + ((((lane >> 4)) ^ (lane & 7)) << 4);  // k-step 0; k-step 1 = ^64
   const int aoff = (wr * 16 * WM) * ROW_BYTES;
-  const int woff = A_BYTES + (wc * 16 * WN) * ROW_BYTES;
+  const int woff = (wc * 16 * WN) * ROW_BYTES;
 
   f32x4_t acc[WN][WM];
 #pragma unroll
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 
   const int nt = p.K / BK;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) stage_one(s, 0, 0);
+  for (int s = 0; s < NS; ++s) stage_one(s, 0, 0, 0);
   if constexpr (VARIANT == 0) {
     // baseline structure kept for in-process A/B runs: stage the next tile up front, then all fragment
     // reads of a k-step followed by its MFMAs (compiler-scheduled)
@@ -216,17 +219,18 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
       __syncthreads();
       if (t + 1 < nt) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) stage_one(s, (t + 1) & 1, t + 1);
+        for (int s = 0; s < NS; ++s) stage_one(s, (t + 1) & 1, (t + 1) & 1, t + 1);
       }
-      const char* base = smem + (t & 1) * STAGE_BYTES;
+      const char* abase = smem + (t & 1) * A_BYTES;
+      const char* wbase = smem + W_REGION + (t & 1) * W_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int fo = foff0 ^ (ks << 6);
         bf16x8_t wf[WN], af[WM];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(base + woff + j * 16 * ROW_BYTES + fo);
+        for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(wbase + woff + j * 16 * ROW_BYTES + fo);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8_t*)(base + aoff + i * 16 * ROW_BYTES + fo);
+        for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8_t*)(abase + aoff + i * 16 * ROW_BYTES + fo);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -241,14 +245,31 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   //    behind MFMAs instead of fronting the tile while the matrix pipe idles);
   //  * the WN W-fragments of a k-step stay resident, A-fragments are read one m-tile ahead of the MFMAs
   //    that consume them, the next k-step's W-fragments behind the last m-tiles.
+  //  * VARIANT 2: the W tile (the operand that streams cold from HBM: every layer has its own weights)
+  //    is prefetched TWO k-tiles ahead into a 3-deep W ring, the A tile (L2-resident activations) one
+  //    ahead.  A DMAs are issued before the W DMAs of an iteration, so the counted `s_waitcnt vmcnt(SW)`
+  //    at the barrier retires tile t+1's operands and leaves the W(t+2) transfers in flight across it.
+  if constexpr (VARIANT == 2) {
+#pragma unroll
+    for (int s = SA; s < NS; ++s) stage_one(s, 0, 1, min(1, nt - 1));
+  }
+  int wcur = 0;
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();  // s_waitcnt vmcnt(0) + barrier: tile t landed, buffer (t+1)&1 free
-    const char* base = smem + (t & 1) * STAGE_BYTES;
-    const char* wb = base + woff;
-    const char* ab = base + aoff;
-    // the tile after the last is a harmless re-load of the last one (keeps the loop body branch-free)
-    const int kt_next = min(t + 1, nt - 1);
-    const int buf_next = (t + 1) & 1;
+    if constexpr (VARIANT == 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();  // s_waitcnt vmcnt(0) + barrier: tile t landed, buffer (t+1)&1 free
+    }
+    const int wslot = VARIANT == 2 ? wcur : (t & 1);
+    const char* wb = smem + W_REGION + wslot * W_BYTES + woff;
+    const char* ab = smem + (t & 1) * A_BYTES + aoff;
+    // tiles past the last are harmless re-loads of the last one (keeps the loop body branch-free)
+    const int kt_a = min(t + 1, nt - 1);
+    const int kt_w = VARIANT == 2 ? min(t + 2, nt - 1) : kt_a;
+    const int abuf_next = (t + 1) & 1;
+    const int wbuf_next = VARIANT == 2 ? (wcur == 0 ? 2 : wcur - 1) : abuf_next;   // (wcur + 2) % 3
+    wcur = wcur == 2 ? 0 : wcur + 1;
     bf16x8_t wf[2][WN], af[2];
 #pragma unroll
     for (int j = 0; j < WN; ++j) wf[0][j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + foff0);
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 #pragma unroll
         for (int q = 0; q < S_PER_IT; ++q) {
           const int s = it * S_PER_IT + q;
-          if (s < NS) { stage_one(s, buf_next, kt_next); ++nst; }
+          if (s < NS) { stage_one(s, abuf_next, wbuf_next, s < SA ? kt_a : kt_w); ++nst; }
         }
         // prefetch the next A fragment (next m-tile, or m-tile 0 of the next k-step)
         if (i + 1 < WM) af[cur ^ 1] = *(const bf16x8_t*)(ab + (i + 1) * 16 * ROW_BYTES + fo);
@@ -327,10 +348,10 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 
 namespace {
 
-template <int WM, int WN, int VARIANT = 1>
+template <int WM, int WN, int VARIANT = 2>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
-  constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
+  constexpr int LDS = (2 * BM + (VARIANT == 2 ? 3 : 2) * BN) * ROW_BYTES;
   TdGemmParams p = p0;
   p.tiles_m0 = (p.M + BM - 1) / BM;
   p.tiles_m = p.tiles_m0 + (p.g_M > 0 ? (p.g_M + BM - 1) / BM : 0);
@@ -378,12 +399,14 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_ARG(((uintptr_t)p.g_A | (uintptr_t)p.g_W | (uintptr_t)p.g_C) % 16 == 0, "td_gemm: grouped pointers must be 16-byte aligned");
   }
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K);
-  switch (cfg) {
-    case 1: return launch_cfg<8, 1>(p, stream);
-    case 2: return launch_cfg<1, 4>(p, stream);
-    case 3: return launch_cfg<9, 3>(p, stream);
-    case 10: return launch_cfg<8, 4, 0>(p, stream);   // baseline loop structure, A/B only
+  switch (cfg) {   // 0-3: shipped pipeline (VARIANT 2); 1x / 3x: earlier loop structures kept for in-process A/B
+    case 1: return launch_cfg<8, 1, 2>(p, stream);
+    case 2: return launch_cfg<1, 4, 2>(p, stream);
+    case 3: return launch_cfg<9, 3, 2>(p, stream);
+    case 10: return launch_cfg<8, 4, 0>(p, stream);
     case 13: return launch_cfg<9, 3, 0>(p, stream);
-    default: return launch_cfg<8, 4>(p, stream);
+    case 30: return launch_cfg<8, 4, 1>(p, stream);
+    case 33: return launch_cfg<9, 3, 1>(p, stream);
+    default: return launch_cfg<8, 4, 2>(p, stream);
   }
 }

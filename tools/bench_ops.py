@@ -62,6 +62,32 @@ def bench_gemmcfg():
         print(f"M={M0}+{M1} N={N} K={K}:  " + "   ".join(f"cfg{c}: {best[c]:7.3f} ms {fl/best[c]/1e9:7.1f} TF/s" for c in cfgs), flush=True)
 
 
+def bench_gemmcold():
+    """Tile/pipeline variants with L3-warm weights (one W re-used) vs cold weights (cycling a 1 GB pool, as in
+    the real denoise loop where every layer's weights stream from HBM).  Interleaved rounds, best-of."""
+    import sys
+    cfgs = [int(c) for c in os.environ.get("TD_CFGS", "0,20,3,23").split(",")]
+    for M, N, K in [(4289, 21504, 3072), (4289, 3072, 15360), (4289, 9216, 3072), (4289, 12288, 3072), (4289, 3072, 12288)]:
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(max(2, int(1.2e9 // (N * K * 2))))]
+        b = torch.randn(N, device="cuda").bfloat16()
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        fl = 2.0 * M * N * K
+        state = {"i": 0}
+        def run(cfg, cold):
+            def f():
+                if cold:
+                    state["i"] = (state["i"] + 1) % len(pool)
+                _hip.linear_grouped2(x, pool[state["i"] if cold else 0], b, y, None, None, None, None, tile_cfg=cfg)
+            return f
+        best = {(c, k): 1e9 for c in cfgs for k in (0, 1)}
+        for _ in range(4):
+            for c in cfgs:
+                for k in (0, 1):
+                    best[(c, k)] = min(best[(c, k)], timeit(run(c, k), iters=16, warmup=2))
+        print(f"M={M} N={N} K={K}: " + " | ".join(f"cfg{c} warm {fl/best[(c,0)]/1e9:6.0f} cold {fl/best[(c,1)]/1e9:6.0f}" for c in cfgs) + " TF/s", flush=True)
+
+
 def bench_attn():
     for S, H in [(4289, 24), (4224, 24), (4096, 24), (8192, 24)]:
         qkv = torch.randn(1, S, 3 * H * 128, device="cuda").bfloat16()
