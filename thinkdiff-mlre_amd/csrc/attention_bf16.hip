@@ -49,10 +49,11 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 }  // namespace
 
-template <bool CAUSAL, int NWAVES>
+template <bool CAUSAL, int NWAVES, bool STAGGER>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const TdAttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
+  constexpr int VBUFS = STAGGER ? 3 : 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K tile x 2 | V tile x VBUFS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,21 +97,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const 
     const int chunk = (lane & 15) ^ swz;
     voffK[s] = (unsigned)(g * 4 + srow) * (unsigned)p.ldkv * 2u + (unsigned)(kvhead * D + chunk * 8) * 2u;
   }
-  auto stage = [&](int buf, int t) {
-    char* base = smem + buf * (2 * TILE_BYTES);
+  auto stage = [&](int kslot, int vslot_, int t) {
+    char* kdst = smem + kslot * TILE_BYTES;
+    char* vdst = smem + 2 * TILE_BYTES + vslot_ * TILE_BYTES;
     const unsigned tile_off = (unsigned)t * KV_TILE * (unsigned)p.ldkv * 2u;
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
       const int g = wid + NWAVES * s;
       if (GROUPS % NWAVES == 0 || g < GROUPS) {
         // row part stays in voffset so the descriptor range check sees it: keys >= Skv read as 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(base + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(base + TILE_BYTES + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(kdst + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(vdst + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
       }
     }
   };
 
-  stage(0, 0);
+  stage(0, 0, 0);
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + l31][16 ks + 8 h5 .. +8] -----
   bf16x8_t qf[8];
@@ -137,16 +139,53 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const 
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -1e30f;   // running row max (raw score units)
+  float m_run = -1e30f;   // row max the exponentials are taken against (raw score units)
   float l_run = 0.f;      // this lane-half's partial row sum
   const float c = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c)
   const int q_pos = q0 + l31 + p.causal_offset;   // causal: keys <= q_pos visible
+  bf16x8_t pf[2][2];      // [kb][s] B-operand fragments of P^T (live across the barrier for the deferred half)
+
+  // O^T += V^T . P^T for one KV tile
+  auto pv = [&](const char* vbuf) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          bf16x4_t v01[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int row = kb * 32 + 16 * s + 8 * jj + vrow_base;
+            const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+            const int off = row * 256 + (((4 * db + vchunk_base) ^ swz) << 4) + 8 * (vp & 1);
+            v01[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(vbuf + off));
+          }
+          bf16x8_t vf;
+          vf[0] = v01[0][0]; vf[1] = v01[0][1]; vf[2] = v01[0][2]; vf[3] = v01[0][3];
+          vf[4] = v01[1][0]; vf[5] = v01[1][1]; vf[6] = v01[1][2]; vf[7] = v01[1][3];
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], o[db], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // Ping-pong: the two waves that share a SIMD (w and w + NWAVES/2) run half a tile apart.  The second
+  // half of the workgroup defers each tile's P.V product until after the next barrier, so its matrix work
+  // overlaps the first half's softmax (VALU) and vice versa; in lockstep both waves would sit in their
+  // softmax at the same time with the matrix pipe idle.  The deferred product still reads V(t-1) while
+  // tile t+1 is being staged, hence the 3-deep V ring (K stays 2-deep).
+  const bool deferred = STAGGER && wid >= NWAVES / 2;
+  int vslot = 0;  // t % VBUFS
 
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();  // vmcnt(0) + barrier: tile t landed; buffer (t+1)&1 no longer read
-    if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-    const char* kbuf = smem + (t & 1) * (2 * TILE_BYTES);
-    const char* vbuf = kbuf + TILE_BYTES;
+    __syncthreads();  // vmcnt(0) + barrier: tile t landed; K buffer (t+1)&1 and V slot (t+1)%VBUFS are free
+    const int vnext = vslot + 1 == VBUFS ? 0 : vslot + 1;
+    if (t + 1 < nt) stage((t + 1) & 1, vnext, t + 1);
+    const char* kbuf = smem + (t & 1) * TILE_BYTES;
+    const char* vbuf = smem + 2 * TILE_BYTES + vslot * TILE_BYTES;
+    if (deferred && t > 0) pv(smem + 2 * TILE_BYTES + (vslot == 0 ? VBUFS - 1 : vslot - 1) * TILE_BYTES);
+    vslot = vnext;
 
     // ---- S^T = K . Q^T ------------------------------------------------------------------------
     f32x16_t st[2];
@@ -182,12 +221,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
     mx = half_swap_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    m_run = m_new;
-    const float mc = m_new * c;
+    // Deferred rescale: O and l are rescaled only when some row's max grew by more than 2^RESCALE_LOG2
+    // (P <= 2^8 then, harmless in the fp32 accumulators and in bf16 P); rows are otherwise exponentiated
+    // against their stale max.  Every row is finite after tile 0: m_run starts at -1e30 so tile 0 rescales.
+    constexpr float RESCALE_LOG2 = 8.0f;
+    if (__any((mx - m_run) * c > RESCALE_LOG2)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
-    bf16x8_t pf[2][2];  // [kb][s] B-operand fragments of P^T
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -203,35 +252,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const 
         pf[kb][s] = __builtin_bit_cast(bf16x8_t, pk);
       }
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    l_run += psum;
 
-    // ---- O^T += V^T . P^T ------------------------------------------------------------------------
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          bf16x4_t v01[2];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int row = kb * 32 + 16 * s + 8 * jj + vrow_base;
-            const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-            const int off = row * 256 + (((4 * db + vchunk_base) ^ swz) << 4) + 8 * (vp & 1);
-            v01[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(vbuf + off));
-          }
-          bf16x8_t vf;
-          vf[0] = v01[0][0]; vf[1] = v01[0][1]; vf[2] = v01[0][2]; vf[3] = v01[0][3];
-          vf[4] = v01[1][0]; vf[5] = v01[1][1]; vf[6] = v01[1][2]; vf[7] = v01[1][3];
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], o[db], 0, 0, 0);
-        }
-      }
-    }
+    if (!deferred) pv(vbuf);
   }
+  if (deferred) pv(smem + 2 * TILE_BYTES + (vslot == 0 ? VBUFS - 1 : vslot - 1) * TILE_BYTES);
 
   // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] --------------------
   const float l_tot = half_swap_sum(l_run);
@@ -261,20 +286,26 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
                "td_attention: per-batch operand exceeds the 4 GiB buffer-descriptor range");
   TD_CHECK_ARG(((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0, "td_attention: pointers must be 16-byte aligned");
   constexpr int NW = 8;
-  constexpr int LDS = 4 * TILE_BYTES;  // 2 buffers x (K + V)
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
+  const bool stagger = p.variant != 1;  // variant 1 = lockstep structure, kept for in-process A/B
+  const int lds = (2 + (stagger ? 3 : 2)) * TILE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<false, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<true, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<false, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<true, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
     attr_set = true;
   }
-  if (p.causal)
-    hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW>), grid, dim3(NW * 64), LDS, stream, q);
-  else
-    hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW>), grid, dim3(NW * 64), LDS, stream, q);
+  if (p.causal) {
+    if (stagger) hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW, true>), grid, dim3(NW * 64), lds, stream, q);
+    else hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW, false>), grid, dim3(NW * 64), lds, stream, q);
+  } else {
+    if (stagger) hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
+    else hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW, false>), grid, dim3(NW * 64), lds, stream, q);
+  }
   TD_CHECK_LAUNCH();
   return 0;
 }

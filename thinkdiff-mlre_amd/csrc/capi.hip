@@ -56,6 +56,13 @@ int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* 
   return td_gemm_launch(p, (hipStream_t)stream);
 }
 
+static int g_attn_variant = 1;  // lockstep measured faster than ping-pong (softmax VALU, not matrix/VALU phase overlap, is the limiter)
+int td_attention_set_variant(int variant) {
+  const int prev = g_attn_variant;
+  g_attn_variant = variant;
+  return prev;
+}
+
 int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void* k, const void* v,
                       int64_t ldkv, int64_t kv_bstride, void* o, int64_t ldo, int64_t o_bstride,
                       int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,
@@ -65,7 +72,7 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
   p.batch = batch; p.Sq = Sq; p.Skv = Skv; p.Hq = Hq; p.Hkv = Hkv; p.head_dim = head_dim;
   p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo;
   p.q_bstride = q_bstride; p.kv_bstride = kv_bstride; p.o_bstride = o_bstride;
-  p.scale = scale; p.causal = causal; p.causal_offset = Skv - Sq;
+  p.scale = scale; p.causal = causal; p.causal_offset = Skv - Sq; p.variant = g_attn_variant;
   return td_attn_launch(p, (hipStream_t)stream);
 }
 

@@ -62,6 +62,7 @@ def _declare(L):
         "td_flux_denoise": [vp, vp, vp, i32, vp],
         "td_flux_trace_begin": [vp, i32],
         "td_flux_trace_end": [vp, vp, vp, vp, vp],
+        "td_attention_set_variant": [i32],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
     }
     for name, args in sig.items():

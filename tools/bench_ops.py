@@ -93,8 +93,15 @@ def bench_attn():
         qkv = torch.randn(1, S, 3 * H * 128, device="cuda").bfloat16()
         out = torch.empty(1, S, H * 128, device="cuda", dtype=torch.bfloat16)
         q, k, v = qkv[:, :, :H * 128], qkv[:, :, H * 128:2 * H * 128], qkv[:, :, 2 * H * 128:]
-        ms = timeit(lambda: _hip.attention(q, k, v, out, H, H))
+        best = {0: 1e9, 1: 1e9}
+        for _ in range(4):
+            for var in (0, 1):
+                _hip.lib().td_attention_set_variant(var)
+                best[var] = min(best[var], timeit(lambda: _hip.attention(q, k, v, out, H, H), iters=10, warmup=2))
+        _hip.lib().td_attention_set_variant(0)
+        ms = best[0]
         fl = 4.0 * S * S * H * 128
+        print(f"   ping-pong {fl/best[0]/1e9:7.1f} TF/s   lockstep {fl/best[1]/1e9:7.1f} TF/s")
         qh = q.reshape(1, S, H, 128).transpose(1, 2)
         kh = k.reshape(1, S, H, 128).transpose(1, 2)
         vh = v.reshape(1, S, H, 128).transpose(1, 2)
