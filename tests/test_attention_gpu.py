@@ -11,6 +11,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=["lean", "lockstep"], autouse=True)
+def all_variants(request, hip):
+    """Every kernel structure behind td_attention_bf16 must pass every case."""
+    prev = hip.lib().td_attention_set_variant(request.param)
+    yield
+    hip.lib().td_attention_set_variant(prev)
+
+
 def _ref(q, k, v, Hq, Hkv, causal):
     B, Sq, _ = q.shape
     Skv = k.shape[1]

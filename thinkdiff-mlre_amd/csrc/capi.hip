@@ -56,7 +56,7 @@ int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* 
   return td_gemm_launch(p, (hipStream_t)stream);
 }
 
-static int g_attn_variant = 1;  // lockstep measured faster than ping-pong (softmax VALU, not matrix/VALU phase overlap, is the limiter)
+static int g_attn_variant = 0;
 int td_attention_set_variant(int variant) {
   const int prev = g_attn_variant;
   g_attn_variant = variant;

@@ -44,7 +44,7 @@ struct TdAttnParams {
   float scale = 0.f;
   int causal = 0, causal_offset = 0;  // key visible iff key <= q + causal_offset
   int q_per_kv = 1;                   // filled by the launcher
-  int variant = 1;                    // 1: lockstep waves (shipped), 0: ping-pong waves + 3-deep V ring (A/B)
+  int variant = 0;                    // 0: shipped (lean stream), 1: first lockstep kernel (A/B only)
 };
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);

@@ -101,7 +101,7 @@ def bench_attn():
         _hip.lib().td_attention_set_variant(0)
         ms = best[0]
         fl = 4.0 * S * S * H * 128
-        print(f"   ping-pong {fl/best[0]/1e9:7.1f} TF/s   lockstep {fl/best[1]/1e9:7.1f} TF/s")
+        print(f"   lean {fl/best[0]/1e9:7.1f} TF/s   lockstep {fl/best[1]/1e9:7.1f} TF/s")
         qh = q.reshape(1, S, H, 128).transpose(1, 2)
         kh = k.reshape(1, S, H, 128).transpose(1, 2)
         vh = v.reshape(1, S, H, 128).transpose(1, 2)
