@@ -162,6 +162,45 @@ int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, dou
 /* n Euler steps in place; sigmas: n+1 host floats */
 int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream);
 
+/* ---- Qwen2-VL text decoder: hidden states at `model.norm` + KV-cached decoding -------------------------
+ * Replaces the vLLM fork's model runner behind `self.mllama.generate(inputs, sampling_params)` with
+ * `return_hidden_states=True` (thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:790-816,1083-1089;
+ * thinkdiff/models/mllama_vllm_generate_1.py:382-413,586,614-615): `prompt_hidden_states` /
+ * `outputs[0].hidden_states` are `hidden_out` of the prompt tokens / of the generated tokens.
+ * Parameters use the Hugging Face names (model.embed_tokens.weight, model.layers.N.self_attn.q_proj.weight,
+ * ..., model.norm.weight, lm_head.weight). */
+typedef struct td_qwen2 td_qwen2;
+typedef struct TdQwen2Config {
+  int hidden;            /* 3584 (7B) / 1536 (2B) */
+  int num_layers;        /* 28 */
+  int num_heads;         /* 28 / 12 */
+  int num_kv_heads;      /* 4 / 2 */
+  int head_dim;          /* 128 */
+  int intermediate;      /* 18944 / 8960 */
+  int vocab;             /* 152064 / 151936 */
+  int tie_embeddings;    /* 0 / 1 */
+  int mrope_section[3];  /* 16,24,24 */
+  float rms_eps;         /* 1e-6 */
+  float rope_theta;      /* 1e6 */
+} TdQwen2Config;
+
+int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out);
+void td_qwen2_destroy(td_qwen2* f);
+int td_qwen2_num_params(const td_qwen2* f);
+int td_qwen2_param_info(const td_qwen2* f, int idx, char* name_buf, int buf_len, int64_t* count);
+int td_qwen2_load_param(td_qwen2* f, const char* name, const void* src, int64_t count, void* stream);
+int td_qwen2_init_random(td_qwen2* f, uint64_t seed, float std, void* stream);
+/* n new tokens at cache positions [pos0, pos0+n): token_ids int32[n] OR inputs_embeds bf16[n,hidden] (device),
+ * position_ids int32[3,n] (M-RoPE t/h/w streams, device); hidden_out bf16[n,hidden] = model.norm output (may be
+ * NULL); logits_last bf16[vocab] of the last token (may be NULL).  pos0 = 0 is a prefill; pos0 > 0 continues. */
+int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
+                     int pos0, void* hidden_out, void* logits_last, void* stream);
+
+/* Qwen2 building blocks */
+int td_embed_gather_bf16(const int* ids, const void* table, void* out, int n, int D, int vocab, void* stream);
+int td_silu_mul_bf16(const void* gate_up, void* out, int rows, int I, void* stream);
+int td_mrope_table(const int* pos3n, int n, const int* sections3, float theta, int round_bf16, float* cos, float* sin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,11 +59,35 @@ def flux_case(seed):
             "pinned_by": "oracle itself (diffusers 0.31.0 not available): drift check only", **META}
 
 
+def qwen2_case(seed):
+    """expected = transformers Qwen2VLTextModel(tiny).last_hidden_state (eager attention), fp32 and bf16."""
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLTextConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
+    from oracle import qwen2vl_ref as Q
+    cfg = Q.tiny_config()
+    hc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
+                           num_key_value_heads=cfg.num_kv_heads, intermediate_size=cfg.intermediate, vocab_size=cfg.vocab,
+                           rms_norm_eps=1e-6, max_position_embeddings=1024, bos_token_id=None, eos_token_id=None, pad_token_id=None,
+                           rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]})
+    hc._attn_implementation = "eager"
+    m = Qwen2VLTextModel(hc).eval()
+    sd = Q.init_weights(cfg, seed=seed, dtype=torch.float32)
+    m.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=False)
+    n = 41
+    ids = torch.randint(0, cfg.vocab, (1, n), generator=torch.Generator().manual_seed(seed + 1))
+    pos = torch.stack([torch.arange(n), torch.arange(n) // 3 + 2, (torch.arange(n) * 2) % 11])[:, None, :]
+    with torch.no_grad():
+        h32 = m(input_ids=ids, position_ids=pos).last_hidden_state[0].clone()
+        h16 = m.bfloat16()(input_ids=ids, position_ids=pos).last_hidden_state[0].clone()
+    return {"seed": seed, "n": n, "ids": ids[0].clone(), "pos": pos[:, 0].clone(), "hidden_fp32": h32, "hidden_bf16": h16, **META}
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.save(aligner_case(1408, 4096, 257, 11, torch.float32), os.path.join(HERE, "aligner_clip_fp32.pt"))
     torch.save(aligner_case(1408, 4096, 257, 12, torch.bfloat16), os.path.join(HERE, "aligner_clip_bf16.pt"))
     torch.save(aligner_case(3584, 4096, 128, 13, torch.bfloat16), os.path.join(HERE, "aligner_lvlm7b_bf16.pt"))
     torch.save(flux_case(21), os.path.join(HERE, "flux_tiny_oracle.pt"))
+    torch.save(qwen2_case(31), os.path.join(HERE, "qwen2vl_tiny.pt"))
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

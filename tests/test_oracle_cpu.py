@@ -7,6 +7,7 @@ import torch
 
 from oracle import aligner_ref as A
 from oracle import flux_ref as R
+from oracle import qwen2vl_ref as Q
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -83,3 +84,43 @@ def test_flux_oracle_structure():
     # timestep embedding is [cos | sin]
     e = R.timestep_proj(torch.tensor([0.0]))
     assert torch.all(e[0, :128] == 1) and torch.all(e[0, 128:] == 0)
+
+
+def test_qwen2_oracle_matches_transformers_golden():
+    """Golden hidden states came from transformers' Qwen2VLTextModel (tiny config, 3 distinct M-RoPE streams)."""
+    fx = _load("qwen2vl_tiny.pt")
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=fx["seed"], dtype=torch.float32)
+    pos = fx["pos"].to(torch.int32)
+    h32, kv = Q.text_model_hidden(sd, cfg, pos, token_ids=fx["ids"])
+    assert (h32 - fx["hidden_fp32"]).abs().max() < 1e-5
+    h16, _ = Q.text_model_hidden({k: v.bfloat16() for k, v in sd.items()}, cfg, pos, token_ids=fx["ids"])
+    assert (h16.float() - fx["hidden_bf16"].float()).abs().max() <= 2 * 0.03125   # two bf16 ulps at |h| ~ 4
+    # KV-cached continuation is the same function
+    a, kv1 = Q.text_model_hidden(sd, cfg, pos[:, :30], token_ids=fx["ids"][:30])
+    b, _ = Q.text_model_hidden(sd, cfg, pos[:, 30:], token_ids=fx["ids"][30:], past=kv1)
+    assert (torch.cat([a, b]) - h32).abs().max() < 1e-5
+
+
+def test_qwen2_live_against_transformers_if_available():
+    """Same check against the installed transformers module itself (skipped where the API differs)."""
+    tf = pytest.importorskip("transformers.models.qwen2_vl.modeling_qwen2_vl")
+    cfgmod = pytest.importorskip("transformers.models.qwen2_vl.configuration_qwen2_vl")
+    cfg = Q.tiny_config(num_layers=1)
+    try:
+        hc = cfgmod.Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=1, num_attention_heads=cfg.num_heads,
+                                      num_key_value_heads=cfg.num_kv_heads, intermediate_size=cfg.intermediate, vocab_size=cfg.vocab,
+                                      rms_norm_eps=1e-6, max_position_embeddings=256, bos_token_id=None, eos_token_id=None, pad_token_id=None,
+                                      rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]})
+    except Exception as e:  # pragma: no cover - other transformers versions
+        pytest.skip(f"config API differs: {e}")
+    hc._attn_implementation = "eager"
+    m = tf.Qwen2VLTextModel(hc).eval()
+    sd = Q.init_weights(cfg, seed=2, dtype=torch.float32)
+    m.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=False)
+    ids = torch.randint(0, cfg.vocab, (1, 19), generator=torch.Generator().manual_seed(0))
+    pos = torch.stack([torch.arange(19), torch.arange(19) // 2, torch.arange(19) % 5])[:, None, :]
+    with torch.no_grad():
+        ref = m(input_ids=ids, position_ids=pos).last_hidden_state[0]
+    mine, _ = Q.text_model_hidden(sd, cfg, pos[:, 0].to(torch.int32), token_ids=ids[0])
+    assert (ref - mine).abs().max() < 1e-5

@@ -1,0 +1,111 @@
+"""GPU parity of the Qwen2-VL text-decoder engine (td_qwen2_*) against the CPU oracle (oracle/qwen2vl_ref.py,
+pinned to transformers' Qwen2VLTextModel in tests/test_oracle_cpu.py).
+
+Tolerance: same bf16 rounding points, different fp32 summation order -> relative RMSE <= 2e-2 of the hidden
+state RMS vs the bf16 oracle, and no further from the fp32 oracle than 1.5x the bf16 oracle itself is.
+"""
+import pytest
+import torch
+
+from oracle import qwen2vl_ref as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def _engine(cfg, sd, max_len=512):
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    e = Qwen2VLTextEngine(Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers,
+                                            num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                                            intermediate_size=cfg.intermediate, vocab_size=cfg.vocab,
+                                            tie_word_embeddings=cfg.tie_embeddings), max_model_len=max_len)
+    e.load_state_dict(sd)
+    return e
+
+
+@pytest.mark.parametrize("n,tie", [(37, False), (300, True)])
+def test_prefill_hidden_states_match_oracle(hip, n, tie):
+    cfg = Q.tiny_config(tie_embeddings=tie)
+    sd = Q.init_weights(cfg, seed=n)
+    e = _engine(cfg, sd)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, cfg.vocab, (n,), generator=g).to(torch.int32)
+    # non-trivial M-RoPE streams (an "image" block in the middle uses a 2-D grid)
+    pos = torch.stack([torch.arange(n), torch.arange(n) // 3 + 2, (torch.arange(n) * 2) % 11]).to(torch.int32)
+    ref16, _ = Q.text_model_hidden(sd, cfg, pos, token_ids=ids.long())
+    ref32, _ = Q.text_model_hidden({k: v.float() for k, v in sd.items()}, cfg, pos, token_ids=ids.long())
+    hid, logits = e.forward(pos, ids, want_logits=True)
+    torch.cuda.synchronize()
+    e16, e32, eref = _rel(hid, ref16), _rel(hid, ref32), _rel(ref16, ref32)
+    print(f"rel-RMSE hip~bf16 {e16:.4f} hip~fp32 {e32:.4f} bf16~fp32 {eref:.4f}")
+    assert e16 < 2e-2 and e32 < 1.5 * eref + 2e-3
+    lref = Q.lm_logits(sd, cfg, ref16[-1])
+    assert _rel(logits, lref) < 3e-2
+
+
+def test_kv_cached_decode_equals_prefill(hip):
+    """Prefill 40 tokens, then feed 9 more one at a time through the KV cache: hidden states must equal a single
+    49-token prefill (and the oracle)."""
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=5)
+    e = _engine(cfg, sd)
+    g = torch.Generator().manual_seed(2)
+    n0, n1 = 40, 9
+    ids = torch.randint(0, cfg.vocab, (n0 + n1,), generator=g).to(torch.int32)
+    pos = Q.text_position_ids(n0 + n1)
+    full, _ = e.forward(pos, ids)
+    a, _ = e.forward(pos[:, :n0], ids[:n0])
+    steps = [e.forward(pos[:, n0 + i:n0 + i + 1], ids[n0 + i:n0 + i + 1], pos0=n0 + i)[0] for i in range(n1)]
+    torch.cuda.synchronize()
+    inc = torch.cat([a] + steps)
+    assert _rel(inc, full) < 5e-3
+    ref, _ = Q.text_model_hidden(sd, cfg, pos, token_ids=ids.long())
+    assert _rel(inc, ref) < 2e-2
+
+
+def test_get_embed_teacher_forced(hip):
+    """ThinkDiff-LVLM get_embed: hidden states of forced output tokens -> aligner, all embedding_type selections."""
+    from oracle import aligner_ref as A
+    from thinkdiff.models.mllama_vllm_t5_embed_decoder_2 import MllamaVllmT5EmbedDecoderForConditionalGeneration_5
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=9)
+    asd = A.init_weights(cfg.hidden, 4096, seed=4)
+    m = MllamaVllmT5EmbedDecoderForConditionalGeneration_5(
+        Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
+                          num_key_value_heads=cfg.num_kv_heads, intermediate_size=cfg.intermediate, vocab_size=cfg.vocab),
+        vllm_config={"max_model_len": 256, "max_tokens": 6, "min_tokens": 6})
+    m.mllama.load_state_dict(sd)
+    m.load_state_dict(asd)
+    g = torch.Generator().manual_seed(3)
+    prompt = torch.randint(0, cfg.vocab, (20,), generator=g).tolist()
+    forced = torch.randint(0, cfg.vocab, (6,), generator=g).tolist()
+    pos = Q.text_position_ids(26)
+    ref_h, _ = Q.text_model_hidden(sd, cfg, pos, token_ids=torch.tensor(prompt + forced))
+    # LVLM path: aligner Linear layers in bf16, T5LayerNorm in fp32 (weight fp32) -> cast once
+    def ref_aligner(h):
+        y = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(h, asd["mm_projector.0.weight"], asd["mm_projector.0.bias"])),
+                                       asd["mm_projector.2.weight"], asd["mm_projector.2.bias"])
+        return A.t5_layer_norm(y.float(), asd["mm_projector.3.weight"].float()).bfloat16()
+    for et, sl in [("both", slice(0, 26)), ("input_embed", slice(0, 20)), ("input_no_system", slice(14, 20)), ("output_embed", slice(20, 26))]:
+        embs, texts = m.get_embed([{"prompt_token_ids": prompt}], embedding_type=et, need_process=False, forced_output_ids=[forced])
+        torch.cuda.synchronize()
+        assert embs[0].shape == (sl.stop - sl.start, 4096) and texts == [" ".join(map(str, forced))]
+        assert _rel(embs[0], ref_aligner(ref_h[sl])) < 3e-2
+
+
+def test_sampling_is_seeded_and_respects_lengths(hip):
+    cfg = Q.tiny_config()
+    e = _engine(cfg, Q.init_weights(cfg, seed=1))
+    from thinkdiff.models.qwen2_vl import SamplingParams
+    sp = SamplingParams(temperature=0.6, top_p=0.9, max_tokens=8, min_tokens=8, ignore_eos=True)
+    runs = []
+    for _ in range(2):
+        g = torch.Generator(device="cuda").manual_seed(42)
+        runs.append(e.generate([1, 2, 3, 4, 5], sp, generator=g))
+    assert runs[0]["token_ids"] == runs[1]["token_ids"] and len(runs[0]["token_ids"]) == 8
+    assert runs[0]["hidden_states"].shape == (8, cfg.hidden) and runs[0]["prompt_hidden_states"].shape == (5, cfg.hidden)

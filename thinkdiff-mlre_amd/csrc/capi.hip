@@ -137,4 +137,14 @@ int td_aligner_mlp2x_bf16(const void* x, int64_t ldx, int M, int K, int hidden, 
   return td_norm_rows_launch(n, (hipStream_t)stream);
 }
 
+int td_embed_gather_bf16(const int* ids, const void* table, void* out, int n, int D, int vocab, void* stream) {
+  return td_embed_gather_launch(ids, (const bf16_t*)table, (bf16_t*)out, n, D, vocab, (hipStream_t)stream);
+}
+int td_silu_mul_bf16(const void* gate_up, void* out, int rows, int I, void* stream) {
+  return td_silu_mul_launch((const bf16_t*)gate_up, (bf16_t*)out, rows, I, (hipStream_t)stream);
+}
+int td_mrope_table(const int* pos3n, int n, const int* sections3, float theta, int round_bf16, float* cos, float* sin, void* stream) {
+  return td_mrope_table_launch(pos3n, n, sections3, theta, round_bf16, cos, sin, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void td_qk_norm_rope_kernel(const TdQkRopePara
       for (int i = 0; i < 8; ++i) {
         const float other = __shfl_xor(x[i], 8, 16);
         const float rot = (l16 < 8) ? -other : other;
-        y[i] = x[i] * cs[i] + rot * sn[i];
+        // rotate_half == 2: every torch op of the bf16 graph rounds (q*cos, rotate_half(q)*sin, their sum)
+        y[i] = p.rotate_half == 2 ? rbf(x[i] * cs[i]) + rbf(rot * sn[i]) : x[i] * cs[i] + rot * sn[i];
       }
     } else {
 #pragma unroll
@@ -322,6 +323,71 @@ int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t
   TD_CHECK_ARG(G > 0 && G % 2 == 0 && C > 0, "td_cls_avgpool2: grid %d must be even", G);
   const int total = (1 + (G / 2) * (G / 2)) * C;
   hipLaunchKernelGGL(td_cls_avgpool2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, x, y, G, C);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Qwen2-VL helpers (transformers modeling_qwen2_vl.py:117-222, 453-466)
+// ---------------------------------------------------------------------------------------------
+// token embedding gather: out[i,:] = table[ids[i],:]   (16 B per lane)
+__global__ void td_embed_gather_kernel(const int* ids, const bf16_t* table, bf16_t* out, int n, int D, int vocab) {
+  const int row = blockIdx.x;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const u32x4_t* src = (const u32x4_t*)(table + (size_t)id * D);
+  u32x4_t* dst = (u32x4_t*)(out + (size_t)row * D);
+  for (int c = threadIdx.x; c < D / 8; c += blockDim.x) dst[c] = src[c];
+}
+
+int td_embed_gather_launch(const int* ids, const bf16_t* table, bf16_t* out, int n, int D, int vocab, hipStream_t stream) {
+  TD_CHECK_ARG(n > 0 && D % 8 == 0 && vocab > 0, "td_embed_gather: bad shape");
+  hipLaunchKernelGGL(td_embed_gather_kernel, dim3(n), dim3(256), 0, stream, ids, table, out, n, D, vocab);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// SwiGLU combine: out[m, j] = bf16(bf16(silu(gate[m,j])) * up[m,j]) with gate|up the two halves of gu[m, 2I]
+__global__ void td_silu_mul_kernel(const bf16_t* gu, bf16_t* out, int rows, int I) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = I / 8;
+  if (idx >= (long long)rows * per_row) return;
+  const int m = (int)(idx / per_row), c = (int)(idx % per_row);
+  float g[8], u[8];
+  unpack8(*(const u32x4_t*)(gu + (size_t)m * 2 * I + c * 8), g);
+  unpack8(*(const u32x4_t*)(gu + (size_t)m * 2 * I + I + c * 8), u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g[i] = rbf(silu_f(g[i])) * u[i];
+  *(u32x4_t*)(out + (size_t)m * I + c * 8) = pack8(g);
+}
+
+int td_silu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, hipStream_t stream) {
+  TD_CHECK_ARG(rows > 0 && I % 8 == 0, "td_silu_mul: bad shape");
+  const long long n = (long long)rows * (I / 8);
+  hipLaunchKernelGGL(td_silu_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, out, rows, I);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// M-RoPE tables: pos int32 [3, n] (temporal, height, width), sections s0+s1+s2 = 64 rotary pairs.
+// cos/sin[n, 128] fp32 with emb = cat(freqs, freqs); channel j (mod 64) takes its angle from the position
+// stream of its section.  round_bf16: store bf16-rounded values (the tables are cast to the model dtype).
+__global__ void td_mrope_table_kernel(const int* pos, int n, int s0, int s1, float theta, int round_bf16, float* cosT, float* sinT) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * 64) return;
+  const int t = idx / 64, j = idx % 64;
+  const int axis = j < s0 ? 0 : (j < s0 + s1 ? 1 : 2);
+  const float inv_freq = 1.0f / powf(theta, (float)(2 * j) / 128.0f);
+  const float ang = (float)pos[axis * n + t] * inv_freq;
+  float c = cosf(ang), s = sinf(ang);
+  if (round_bf16) { c = rbf(c); s = rbf(s); }
+  cosT[(size_t)t * 128 + j] = c; cosT[(size_t)t * 128 + 64 + j] = c;
+  sinT[(size_t)t * 128 + j] = s; sinT[(size_t)t * 128 + 64 + j] = s;
+}
+
+int td_mrope_table_launch(const int* pos, int n, const int* sections, float theta, int round_bf16, float* cosT, float* sinT, hipStream_t stream) {
+  TD_CHECK_ARG(n > 0 && sections[0] + sections[1] + sections[2] == 64, "td_mrope_table: sections must sum to 64");
+  hipLaunchKernelGGL(td_mrope_table_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, stream, pos, n, sections[0], sections[1], theta, round_bf16, cosT, sinT);
   TD_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,274 @@
+// Qwen2-VL text-decoder engine: hidden-state extraction at `model.norm` (the embedding ThinkDiff-LVLM feeds
+// to its aligner) and KV-cached decoding, on the same GEMM / attention / row kernels as the FLUX engine.
+//
+// Replaces the vLLM fork's Qwen2-VL model runner behind `self.mllama.generate(..., return_hidden_states)`
+// (reference thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:790-816,1083-1089 and
+// thinkdiff/models/mllama_vllm_generate_1.py:382-413,586,614-615).  Per-layer math follows transformers
+// `Qwen2VLDecoderLayer` (modeling_qwen2_vl.py:453-625), which SURVEY.md 8a row A7 identifies as identical:
+//   h += o_proj(Attn(RMSNorm(h)));  h += down(SiLU(gate(x)) * up(x)), x = RMSNorm(h)
+//   Attn: q/k/v Linear with bias, M-RoPE (rotate_half, 3 position streams merged by mrope_section),
+//   causal GQA softmax(q k^T / sqrt(128)) v, o_proj without bias.
+//
+// Layout: one fused [q | k | v] projection per layer whose k|v columns are written STRAIGHT into the
+// layer's KV cache rows (dual-output GEMM epilogue), so prefill and decode share one code path:
+// `td_qwen2_forward(tokens at positions [pos0, pos0+n))` attends over cache rows [0, pos0+n).
+// Parameters are addressed by their Hugging Face names (model.layers.N.self_attn.q_proj.weight, ...).
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "td_kernels.h"
+#include "../../include/thinkdiff_hip.h"
+
+namespace {
+
+struct QSlot { std::string name; bf16_t* ptr; int64_t count; };
+
+struct QLayer {
+  bf16_t *qkv_w, *qkv_b;   // [(Hq + 2 Hkv) * 128, D]
+  bf16_t* o_w;             // [D, Hq * 128]
+  bf16_t* gu_w;            // [2 I, D] = gate_proj | up_proj
+  bf16_t* down_w;          // [D, I]
+  bf16_t *ln1_w, *ln2_w;   // [D]
+  bf16_t* kv;              // cache [max_tokens, 2 * Hkv * 128]
+};
+
+}  // namespace
+
+struct td_qwen2 {
+  TdQwen2Config cfg;
+  int D = 0, I = 0, Hq = 0, Hkv = 0, max_tokens = 0;
+  bf16_t* arena = nullptr;
+  int64_t arena_elems = 0;
+  std::vector<QSlot> slots;
+  std::unordered_map<std::string, int> index;
+  bf16_t *embed_w, *norm_w, *lm_w;
+  std::vector<QLayer> layers;
+  char* ws = nullptr;
+  bf16_t *h, *xn, *q, *attn, *gu, *act;
+  float *cosT, *sinT;
+};
+
+namespace {
+
+void q_add(td_qwen2* f, const std::string& name, bf16_t* p, int64_t n) {
+  f->index[name] = (int)f->slots.size();
+  f->slots.push_back({name, p, n});
+}
+
+#define TDQ_TRY(expr)         \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) {
+  TD_CHECK_ARG(cfg && out && max_tokens > 0, "td_qwen2_create: bad arguments");
+  TD_CHECK_ARG(cfg->head_dim == 128, "td_qwen2_create: head_dim must be 128");
+  TD_CHECK_ARG(cfg->hidden % 512 == 0 && cfg->intermediate % 64 == 0, "td_qwen2_create: hidden %% 512 and intermediate %% 64 must be 0");
+  TD_CHECK_ARG(cfg->num_heads % cfg->num_kv_heads == 0, "td_qwen2_create: heads must be a multiple of kv heads");
+  TD_CHECK_ARG(cfg->mrope_section[0] + cfg->mrope_section[1] + cfg->mrope_section[2] == 64, "td_qwen2_create: mrope sections must sum to 64");
+  td_qwen2* f = new td_qwen2();
+  f->cfg = *cfg;
+  const int D = f->D = cfg->hidden, I = f->I = cfg->intermediate;
+  const int Hq = f->Hq = cfg->num_heads, Hkv = f->Hkv = cfg->num_kv_heads;
+  const int NQKV = (Hq + 2 * Hkv) * 128;
+  f->max_tokens = max_tokens;
+  f->layers.resize(cfg->num_layers);
+
+  int64_t off = 0;
+  std::vector<std::pair<bf16_t**, int64_t>> fix;
+  auto take = [&](bf16_t** p, int64_t n) { fix.emplace_back(p, off); off += (n + 127) & ~int64_t(127); };
+  take(&f->embed_w, (int64_t)cfg->vocab * D);
+  take(&f->norm_w, D);
+  if (!cfg->tie_embeddings) take(&f->lm_w, (int64_t)cfg->vocab * D);
+  for (auto& l : f->layers) {
+    take(&l.qkv_w, (int64_t)NQKV * D); take(&l.qkv_b, NQKV);
+    take(&l.o_w, (int64_t)D * Hq * 128);
+    take(&l.gu_w, (int64_t)2 * I * D);
+    take(&l.down_w, (int64_t)D * I);
+    take(&l.ln1_w, D); take(&l.ln2_w, D);
+    take(&l.kv, (int64_t)max_tokens * 2 * Hkv * 128);
+  }
+  f->arena_elems = off;
+  hipError_t e = hipMalloc((void**)&f->arena, (size_t)off * 2);
+  if (e != hipSuccess) {
+    td_set_error("td_qwen2_create: hipMalloc of %.2f GiB failed: %s", off * 2.0 / (1 << 30), hipGetErrorString(e));
+    delete f;
+    return TD_ERR_HIP;
+  }
+  for (auto& fx : fix) *fx.first = f->arena + fx.second;
+  if (cfg->tie_embeddings) f->lm_w = f->embed_w;
+
+  q_add(f, "model.embed_tokens.weight", f->embed_w, (int64_t)cfg->vocab * D);
+  q_add(f, "model.norm.weight", f->norm_w, D);
+  if (!cfg->tie_embeddings) q_add(f, "lm_head.weight", f->lm_w, (int64_t)cfg->vocab * D);
+  for (int i = 0; i < cfg->num_layers; ++i) {
+    QLayer& l = f->layers[i];
+    const std::string p = "model.layers." + std::to_string(i) + ".";
+    q_add(f, p + "self_attn.q_proj.weight", l.qkv_w, (int64_t)Hq * 128 * D);
+    q_add(f, p + "self_attn.q_proj.bias", l.qkv_b, Hq * 128);
+    q_add(f, p + "self_attn.k_proj.weight", l.qkv_w + (int64_t)Hq * 128 * D, (int64_t)Hkv * 128 * D);
+    q_add(f, p + "self_attn.k_proj.bias", l.qkv_b + Hq * 128, Hkv * 128);
+    q_add(f, p + "self_attn.v_proj.weight", l.qkv_w + (int64_t)(Hq + Hkv) * 128 * D, (int64_t)Hkv * 128 * D);
+    q_add(f, p + "self_attn.v_proj.bias", l.qkv_b + (Hq + Hkv) * 128, Hkv * 128);
+    q_add(f, p + "self_attn.o_proj.weight", l.o_w, (int64_t)D * Hq * 128);
+    q_add(f, p + "mlp.gate_proj.weight", l.gu_w, (int64_t)I * D);
+    q_add(f, p + "mlp.up_proj.weight", l.gu_w + (int64_t)I * D, (int64_t)I * D);
+    q_add(f, p + "mlp.down_proj.weight", l.down_w, (int64_t)D * I);
+    q_add(f, p + "input_layernorm.weight", l.ln1_w, D);
+    q_add(f, p + "post_attention_layernorm.weight", l.ln2_w, D);
+  }
+
+  const int64_t n = max_tokens;
+  struct Req { void** p; int64_t bytes; };
+  std::vector<Req> reqs = {
+      {(void**)&f->h, n * D * 2}, {(void**)&f->xn, n * D * 2}, {(void**)&f->q, n * Hq * 128 * 2},
+      {(void**)&f->attn, n * Hq * 128 * 2}, {(void**)&f->gu, n * 2 * I * 2}, {(void**)&f->act, n * I * 2},
+      {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
+  };
+  int64_t total = 0;
+  for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
+  e = hipMalloc((void**)&f->ws, (size_t)total);
+  if (e != hipSuccess) {
+    td_set_error("td_qwen2_create: hipMalloc of %.2f GiB workspace failed: %s", total / double(1 << 30), hipGetErrorString(e));
+    (void)hipFree(f->arena);
+    delete f;
+    return TD_ERR_HIP;
+  }
+  (void)hipMemset(f->ws, 0, (size_t)total);
+  int64_t o = 0;
+  for (auto& r : reqs) { *r.p = f->ws + o; o += (r.bytes + 255) & ~int64_t(255); }
+  *out = f;
+  return TD_OK;
+}
+
+void td_qwen2_destroy(td_qwen2* f) {
+  if (!f) return;
+  (void)hipFree(f->arena);
+  (void)hipFree(f->ws);
+  delete f;
+}
+
+int td_qwen2_num_params(const td_qwen2* f) { return f ? (int)f->slots.size() : 0; }
+
+int td_qwen2_param_info(const td_qwen2* f, int idx, char* name_buf, int buf_len, int64_t* count) {
+  TD_CHECK_ARG(f && idx >= 0 && idx < (int)f->slots.size(), "td_qwen2_param_info: index %d out of range", idx);
+  if (name_buf && buf_len > 0) {
+    strncpy(name_buf, f->slots[idx].name.c_str(), buf_len - 1);
+    name_buf[buf_len - 1] = 0;
+  }
+  if (count) *count = f->slots[idx].count;
+  return TD_OK;
+}
+
+int td_qwen2_load_param(td_qwen2* f, const char* name, const void* src, int64_t count, void* stream) {
+  TD_CHECK_ARG(f && name && src, "td_qwen2_load_param: null argument");
+  auto it = f->index.find(name);
+  TD_CHECK_ARG(it != f->index.end(), "td_qwen2_load_param: unknown parameter '%s'", name);
+  const QSlot& s = f->slots[it->second];
+  TD_CHECK_ARG(s.count == count, "td_qwen2_load_param: '%s' expects %lld elements, got %lld", name, (long long)s.count, (long long)count);
+  TD_CHECK_HIP(hipMemcpyAsync(s.ptr, src, (size_t)count * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TD_OK;
+}
+
+int td_qwen2_init_random(td_qwen2* f, uint64_t seed, float std, void* stream) {
+  TD_CHECK_ARG(f, "td_qwen2_init_random: null handle");
+  TDQ_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
+  for (const QSlot& s : f->slots)
+    if (s.name.find("layernorm.weight") != std::string::npos || s.name == "model.norm.weight")
+      TDQ_TRY(td_fill_normal_bf16(s.ptr, s.count, seed ^ (uint64_t)(uintptr_t)s.ptr, 0.05f, 1.0f, stream));
+  return TD_OK;
+}
+
+// Runs n new tokens at cache positions [pos0, pos0 + n) through the decoder.
+//   token_ids  : device int32 [n], or NULL when inputs_embeds is given
+//   inputs_embeds : device bf16 [n, hidden] (token embeddings with the image-token rows replaced by the
+//                vision tower's output), or NULL
+//   position_ids : device int32 [3, n] M-RoPE streams (temporal, height, width); text tokens repeat one value
+//   hidden_out : device bf16 [n, hidden] = model.norm(h)  -- the embedding the reference captures
+//                ("embedding_layer_name: model.norm"); may be NULL
+//   logits_last: device bf16 [vocab] for the LAST of the n tokens (lm_head), or NULL
+int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
+                     int pos0, void* hidden_out, void* logits_last, void* stream) {
+  TD_CHECK_ARG(f && position_ids && (token_ids || inputs_embeds), "td_qwen2_forward: null argument");
+  TD_CHECK_ARG(n > 0 && pos0 >= 0 && pos0 + n <= f->max_tokens, "td_qwen2_forward: positions [%d, %d) exceed the cache capacity %d", pos0, pos0 + n, f->max_tokens);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
+  const int QW = Hq * 128, KVW = 2 * Hkv * 128;
+
+  if (inputs_embeds) TD_CHECK_HIP(hipMemcpyAsync(f->h, inputs_embeds, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));
+  else TDQ_TRY(td_embed_gather_launch(token_ids, f->embed_w, f->h, n, D, f->cfg.vocab, s));
+  // transformers casts the fp32 cos/sin tables to the model dtype before use
+  TDQ_TRY(td_mrope_table_launch(position_ids, n, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
+
+  TdNormParams np;
+  np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = n; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
+  TdQkRopeParams rq;   // q heads in the q buffer
+  rq.qkv = f->q; rq.ld = QW; rq.rows = n; rq.Hq = Hq; rq.Hk = 0; rq.q_col = 0; rq.k_col = 0;
+  rq.cos = f->cosT; rq.sin = f->sinT; rq.rotate_half = 2;
+  TdQkRopeParams rk = rq;  // k heads in the cache rows just written
+  rk.ld = KVW; rk.Hq = Hkv;
+
+  for (int i = 0; i < f->cfg.num_layers; ++i) {
+    const QLayer& l = f->layers[i];
+    bf16_t* kv_new = l.kv + (size_t)pos0 * KVW;
+    np.w = l.ln1_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {  // fused q | k | v projection: q -> scratch, k | v -> this layer's cache rows
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = n; g.N = QW + KVW; g.K = D;
+      g.C = f->q; g.ldc = QW; g.C2 = kv_new; g.ldc2 = KVW; g.n_split = QW;
+      if (QW % 256 == 0) {
+        g.cfg = n <= 32 ? -1 : 0;   // the column split needs 256-wide tiles (small-M and 256x256 tiles both are)
+        TDQ_TRY(td_gemm_launch(g, s));
+      } else {
+        TdGemmParams a = g; a.C2 = nullptr; a.N = QW;
+        TDQ_TRY(td_gemm_launch(a, s));
+        TdGemmParams b = g; b.C2 = nullptr; b.W = l.qkv_w + (size_t)QW * D; b.bias = l.qkv_b + QW; b.N = KVW; b.C = kv_new; b.ldc = KVW;
+        TDQ_TRY(td_gemm_launch(b, s));
+      }
+    }
+    rq.qkv = f->q; TDQ_TRY(td_qk_norm_rope_launch(rq, s));
+    rk.qkv = kv_new; TDQ_TRY(td_qk_norm_rope_launch(rk, s));
+    TdAttnParams ap;
+    ap.Q = f->q; ap.ldq = QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW; ap.O = f->attn; ap.ldo = QW;
+    ap.batch = 1; ap.Sq = n; ap.Skv = pos0 + n; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f;
+    ap.causal = 1; ap.causal_offset = pos0;
+    TDQ_TRY(td_attn_launch(ap, s));
+    {  // h += o_proj(attn)
+      TdGemmParams g;
+      g.A = f->attn; g.lda = QW; g.W = l.o_w; g.C = f->h; g.ldc = D; g.res = f->h; g.ldr = D; g.M = n; g.N = D; g.K = QW;
+      TDQ_TRY(td_gemm_launch(g, s));
+    }
+    np.w = l.ln2_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {  // gate | up, SwiGLU, down (+ residual)
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = n; g.N = 2 * I; g.K = D;
+      TDQ_TRY(td_gemm_launch(g, s));
+      TDQ_TRY(td_silu_mul_launch(f->gu, f->act, n, I, s));
+      TdGemmParams d;
+      d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = n; d.N = D; d.K = I;
+      TDQ_TRY(td_gemm_launch(d, s));
+    }
+  }
+  // model.norm -> captured embedding
+  np.w = f->norm_w; np.y = f->xn;
+  TDQ_TRY(td_norm_rows_launch(np, s));
+  if (hidden_out) TD_CHECK_HIP(hipMemcpyAsync(hidden_out, f->xn, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));
+  if (logits_last) {
+    TdGemmParams g;
+    g.A = f->xn + (size_t)(n - 1) * D; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits_last; g.ldc = f->cfg.vocab;
+    g.M = 1; g.N = f->cfg.vocab; g.K = D;
+    TDQ_TRY(td_gemm_launch(g, s));
+  }
+  return TD_OK;
+}
+
+}  // extern "C"

@@ -71,7 +71,7 @@ struct TdQkRopeParams {
   const bf16_t* wqA = nullptr; const bf16_t* wkA = nullptr;  // rows < split (null: no norm)
   const bf16_t* wqB = nullptr; const bf16_t* wkB = nullptr;
   float eps = 1e-6f;
-  int rotate_half = 0;  // 0: interleaved pairs (FLUX), 1: half-split (Qwen2)
+  int rotate_half = 0;  // 0: interleaved pairs (FLUX), 1: half-split fp32, 2: half-split with bf16 op rounding (Qwen2)
 };
 int td_qk_norm_rope_launch(const TdQkRopeParams& p, hipStream_t stream);
 
@@ -81,3 +81,7 @@ int td_temb_combine_silu_launch(const bf16_t* te, const bf16_t* ge, const bf16_t
 int td_euler_step_launch(bf16_t* x, const bf16_t* v, float dt, long long n, hipStream_t stream);
 int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add, hipStream_t stream);
 int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t stream);
+
+int td_embed_gather_launch(const int* ids, const bf16_t* table, bf16_t* out, int n, int D, int vocab, hipStream_t stream);
+int td_silu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, hipStream_t stream);
+int td_mrope_table_launch(const int* pos, int n, const int* sections, float theta, int round_bf16, float* cosT, float* sinT, hipStream_t stream);

@@ -63,6 +63,15 @@ def _declare(L):
         "td_flux_trace_begin": [vp, i32],
         "td_flux_trace_end": [vp, vp, vp, vp, vp],
         "td_attention_set_variant": [i32],
+        "td_qwen2_create": [vp, i32, vp],
+        "td_qwen2_num_params": [vp],
+        "td_qwen2_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
+        "td_qwen2_load_param": [vp, ctypes.c_char_p, vp, i64, vp],
+        "td_qwen2_init_random": [vp, ctypes.c_uint64, f32, vp],
+        "td_qwen2_forward": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
+        "td_embed_gather_bf16": [vp, vp, vp, i32, i32, i32, vp],
+        "td_silu_mul_bf16": [vp, vp, i32, i32, vp],
+        "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
     }
     for name, args in sig.items():
@@ -71,6 +80,8 @@ def _declare(L):
         fn.restype = ctypes.c_int
     L.td_flux_destroy.argtypes = [vp]
     L.td_flux_destroy.restype = None
+    L.td_qwen2_destroy.argtypes = [vp]
+    L.td_qwen2_destroy.restype = None
     L.td_flux_param_elems.argtypes = [vp]
     L.td_flux_param_elems.restype = ctypes.c_int64
     return sig
@@ -234,3 +245,11 @@ def linear_grouped2(x0, w0, b0, y0, x1, w1, b1, y1, act=ACT_NONE, gate0=None, re
                                         ptr(x1), M1, ptr(w1), ptr(b1), ptr(gate1), ptr(res1), ptr(y1),
                                         _rows(x0), _rows(y0), ldr, N, K, act, tile_cfg, stream_ptr()))
     return y0, y1
+
+
+class TdQwen2Config(ctypes.Structure):
+    """Mirror of `struct TdQwen2Config` (include/thinkdiff_hip.h)."""
+    _fields_ = [("hidden", ctypes.c_int), ("num_layers", ctypes.c_int), ("num_heads", ctypes.c_int),
+                ("num_kv_heads", ctypes.c_int), ("head_dim", ctypes.c_int), ("intermediate", ctypes.c_int),
+                ("vocab", ctypes.c_int), ("tie_embeddings", ctypes.c_int), ("mrope_section", ctypes.c_int * 3),
+                ("rms_eps", ctypes.c_float), ("rope_theta", ctypes.c_float)]

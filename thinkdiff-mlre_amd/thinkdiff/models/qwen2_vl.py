@@ -1,0 +1,154 @@
+"""Qwen2-VL text decoder on the HIP engine (`td_qwen2_*`): hidden states at `model.norm` and sampling.
+
+Stands in for the `vllm.LLM(model="Qwen/Qwen2-VL-*", return_hidden_states=True)` object of the reference
+(thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:790-816; thinkdiff/models/mllama_vllm_generate_1.py:382-413)
+for the part of its behaviour the ThinkDiff path uses: `generate()` returning, per request, the prompt tokens'
+and the generated tokens' hidden states at `embedding_layer_name="model.norm"` plus the generated token ids.
+The vision tower is not built: image inputs must arrive as precomputed `image_embeds`.
+"""
+import ctypes
+import dataclasses
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import _hip
+
+
+@dataclasses.dataclass
+class Qwen2VLTextConfig:
+    """Text-side keys of [ext] Qwen/Qwen2-VL-7B-Instruct config.json (2B: 1536 / 12 / 2 / 8960 / 151936 / tied)."""
+    hidden_size: int = 3584
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 28
+    num_key_value_heads: int = 4
+    intermediate_size: int = 18944
+    vocab_size: int = 152064
+    tie_word_embeddings: bool = False
+    mrope_section: Sequence[int] = (16, 24, 24)
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+
+
+@dataclasses.dataclass
+class SamplingParams:
+    """The fields of vllm.SamplingParams the reference sets (mllama_vllm_t5_embed_decoder_2.py:817-823)."""
+    temperature: float = 0.6
+    top_p: float = 0.9
+    max_tokens: int = 128
+    min_tokens: int = 128
+    ignore_eos: bool = True
+    stop_token_ids: Optional[List[int]] = None
+
+
+class Qwen2VLTextEngine:
+    dtype = torch.bfloat16
+
+    def __init__(self, config: Optional[Qwen2VLTextConfig] = None, max_model_len: int = 8192, device="cuda", **kw):
+        self.config = config or Qwen2VLTextConfig(**kw)
+        c = self.config
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _hip.ThinkDiffHipError("Qwen2VLTextEngine runs on the MI355X HIP engine only (device='cuda')")
+        self._L = _hip.lib()
+        cc = _hip.TdQwen2Config(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, 128,
+                                c.intermediate_size, c.vocab_size, int(c.tie_word_embeddings),
+                                (ctypes.c_int * 3)(*c.mrope_section), c.rms_norm_eps, c.rope_theta)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(self._L.td_qwen2_create(ctypes.byref(cc), max_model_len, ctypes.byref(h)))
+        self._h = h
+        self.max_model_len = max_model_len
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.td_qwen2_destroy(h)
+
+    # ---- parameters (Hugging Face names) -----------------------------------------------------------------
+    def param_table(self) -> Dict[str, int]:
+        buf, cnt, out = ctypes.create_string_buffer(256), ctypes.c_int64(), {}
+        for i in range(self._L.td_qwen2_num_params(self._h)):
+            _hip.check(self._L.td_qwen2_param_info(self._h, i, buf, 256, ctypes.byref(cnt)))
+            out[buf.value.decode()] = cnt.value
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        table = self.param_table()
+        missing = [k for k in table if k not in sd]
+        if strict and missing:
+            raise KeyError(f"Qwen2VLTextEngine.load_state_dict: missing {missing[:4]}..")
+        for name, t in sd.items():
+            if name in table:
+                d = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+                _hip.check(self._L.td_qwen2_load_param(self._h, name.encode(), _hip.ptr(d), d.numel(), _hip.stream_ptr()))
+                torch.cuda.current_stream().synchronize()
+        return missing
+
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        _hip.check(self._L.td_qwen2_init_random(self._h, seed, std, _hip.stream_ptr()))
+        return self
+
+    # ---- one decoder pass over n new tokens ---------------------------------------------------------------
+    def forward(self, position_ids, token_ids=None, inputs_embeds=None, pos0: int = 0, want_hidden=True, want_logits=False):
+        """position_ids int32 [3,n]; token_ids int32 [n] or inputs_embeds bf16 [n,hidden].  Returns
+        (hidden [n,hidden] | None, logits_last [vocab] | None)."""
+        pos = position_ids.to(self.device, torch.int32).contiguous()
+        n = pos.shape[1]
+        tok = None if token_ids is None else token_ids.to(self.device, torch.int32).contiguous()
+        emb = None if inputs_embeds is None else inputs_embeds.to(self.device, torch.bfloat16).contiguous()
+        hid = torch.empty(n, self.config.hidden_size, dtype=torch.bfloat16, device=self.device) if want_hidden else None
+        lg = torch.empty(self.config.vocab_size, dtype=torch.bfloat16, device=self.device) if want_logits else None
+        _hip.check(self._L.td_qwen2_forward(self._h, _hip.ptr(tok), _hip.ptr(emb), _hip.ptr(pos), n, pos0,
+                                            _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
+        return hid, lg
+
+    @staticmethod
+    def text_position_ids(n: int, start: int = 0) -> torch.Tensor:
+        return (torch.arange(n, dtype=torch.int32) + start)[None, :].expand(3, n).contiguous()
+
+    # ---- the part of LLM.generate(return_hidden_states=True) the reference consumes ------------------------
+    @torch.no_grad()
+    def generate(self, prompt_token_ids: Sequence[int], sampling: SamplingParams, position_ids=None, inputs_embeds=None,
+                 eos_token_id: Optional[int] = None, generator: Optional[torch.Generator] = None,
+                 forced_output_ids: Optional[Sequence[int]] = None):
+        """Returns dict(prompt_hidden_states [n_prompt,D], hidden_states [n_gen,D], token_ids [n_gen]).
+
+        Sampling is temperature / top-p on the device.  `forced_output_ids` teacher-forces the continuation
+        (the reference samples at T=0.6, so parity of the hidden states is checked on forced ids)."""
+        n_p = len(prompt_token_ids)
+        pos = self.text_position_ids(n_p) if position_ids is None else position_ids
+        next_pos = int(pos.max()) + 1      # M-RoPE: generation continues one past the largest prompt position
+        tok = torch.tensor(list(prompt_token_ids), dtype=torch.int32)
+        prompt_hidden, logits = self.forward(pos, tok if inputs_embeds is None else None, inputs_embeds, 0, True, True)
+        out_ids, out_hidden = [], []
+        stops = set(sampling.stop_token_ids or [])
+        for step in range(sampling.max_tokens):
+            if forced_output_ids is not None:
+                if step >= len(forced_output_ids):
+                    break
+                nxt = int(forced_output_ids[step])
+            else:
+                nxt = self._sample(logits, sampling, generator)
+            out_ids.append(nxt)
+            p1 = torch.full((3, 1), next_pos + step, dtype=torch.int32)
+            h1, logits = self.forward(p1, torch.tensor([nxt], dtype=torch.int32), None, n_p + step, True, True)
+            out_hidden.append(h1)
+            done_eos = (not sampling.ignore_eos) and eos_token_id is not None and nxt == eos_token_id
+            if forced_output_ids is None and step + 1 >= sampling.min_tokens and (done_eos or nxt in stops):
+                break
+        hs = torch.cat(out_hidden) if out_hidden else torch.empty(0, self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
+        return {"prompt_hidden_states": prompt_hidden, "hidden_states": hs, "token_ids": out_ids}
+
+    @staticmethod
+    def _sample(logits: torch.Tensor, sp: SamplingParams, generator=None) -> int:
+        x = logits.float()
+        if sp.temperature <= 0:
+            return int(x.argmax())
+        probs = torch.softmax(x / sp.temperature, dim=-1)
+        if sp.top_p < 1.0:
+            sp_, idx = torch.sort(probs, descending=True)
+            keep = (torch.cumsum(sp_, 0) - sp_) < sp.top_p
+            sp_ = torch.where(keep, sp_, torch.zeros_like(sp_))
+            return int(idx[torch.multinomial(sp_ / sp_.sum(), 1, generator=generator)])
+        return int(torch.multinomial(probs, 1, generator=generator))
