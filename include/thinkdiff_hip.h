@@ -56,6 +56,20 @@ int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* 
                             int64_t ldx, int64_t ldy, int64_t ldr, int N, int K, int act, int tile_cfg,
                             void* stream);
 
+/* 3x3 convolution, stride 1, zero padding 1, over an NHWC bf16 image as an implicit GEMM (no im2col buffer):
+ *   y[H*W, Cout] = conv3x3(x[Hin*Win, Cin]) + bias (+ res[H*W, Cout]);   upsample2x != 0 fuses the nearest 2x
+ * upsample that precedes the conv in Upsample2D (then Hin = H/2, Win = W/2), else Hin = H, Win = W.
+ * w is [Cout, 9*Cin] with k = (ky*3 + kx)*Cin + c (td_conv3x3_pack_weight converts from torch's [Cout,Cin,3,3]).
+ * Cin % 64 == 0, Cout % 8 == 0.  Replaces nn.Conv2d(3x3) of [ext] diffusers AutoencoderKL.decode
+ * (ResnetBlock2D.conv1/conv2, Upsample2D.conv, Decoder.conv_in/conv_out). */
+int td_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, const void* res, void* y,
+                         int H, int W, int Cin, int Cout, int upsample2x, void* stream);
+/* [Cout, Cin, 3, 3] (torch) -> [Cout_pad, 9*Cin_pad] (k = tap*Cin_pad + c), zero filled padding. */
+int td_conv3x3_pack_weight(const void* w_oihw, void* w_packed, int Cout, int Cin, int Cout_pad, int Cin_pad, void* stream);
+/* y[M,N] (fp32) = x[M,K] . w[N,K]^T (+ bias): unrounded rows, e.g. attention scores. */
+int td_linear_f32out_bf16(const void* x, int64_t ldx, const void* w, const void* bias, float* y, int64_t ldy,
+                          int M, int N, int K, void* stream);
+
 /* o[b,s,h*128+d] = softmax(q.k^T * scale (+causal mask)) . v, head_dim 128, fp32 softmax state.
  * q/k/v/o are token-major: row s of batch b at  ptr + b*bstride + s*ld  (elements), head h at
  * column h*128, so the fused QKV projection output is consumed in place.  Hq % Hkv == 0 (GQA).
@@ -161,6 +175,37 @@ int td_flux_trace_begin(td_flux* f, int max_launches);
 int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, double* flops);
 /* n Euler steps in place; sigmas: n+1 host floats */
 int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream);
+
+/* ---- FLUX VAE decoder (AutoencoderKL.decode) -------------------------------------------------------------
+ * Replaces the tail of the drivers' `diffusion_pipe(...)` call: [ext] diffusers 0.31.0 FluxPipeline
+ * `_unpack_latents` + `latents / scaling_factor + shift_factor` + `vae.decode` + `image_processor.postprocess`
+ * (scripts/test/test_blip_vision_t5_decoder_flux_text.py:234-247).  Parameters use the diffusers names
+ * ("decoder.up_blocks.2.resnets.0.conv1.weight", ...), conv weights in torch [Cout,Cin,3,3] layout. */
+typedef struct td_vae td_vae;
+typedef struct TdVaeConfig {
+  int latent_channels;        /* 16 */
+  int out_channels;           /* 3 */
+  int num_blocks;             /* 4 */
+  int block_out_channels[4];  /* 128,256,512,512 */
+  int layers_per_block;       /* 2 */
+  int norm_groups;            /* 32 */
+} TdVaeConfig;
+int td_vae_create(const TdVaeConfig* cfg, int max_latent_h, int max_latent_w, td_vae** out);
+void td_vae_destroy(td_vae* f);
+int td_vae_num_params(const td_vae* f);
+int td_vae_param_info(const td_vae* f, int idx, char* name_buf, int buf_len, int64_t* count);
+int td_vae_load_param(td_vae* f, const char* name, const void* src, int64_t count, void* stream);
+int td_vae_init_random(td_vae* f, uint64_t seed, float std, void* stream);
+/* packed latents bf16 [(h/2)(w/2), 4*latent_channels] (h, w = latent size, h*w % 64 == 0) -> image_u8 [8h,8w,3]
+ * uint8 and/or image_chw bf16 [3,8h,8w] (= vae.decode output); either may be NULL. */
+int td_vae_decode(td_vae* f, const void* packed_latents, int h, int w, float scaling_factor, float shift_factor,
+                  void* image_u8, void* image_chw, void* stream);
+/* GroupNorm (+ optional SiLU) over an NHWC image x[P,C]; workspace: td_groupnorm_workspace_floats() floats. */
+int td_groupnorm_nhwc_bf16(const void* x, void* y, int P, int C, int groups, float eps, const void* gamma,
+                           const void* beta, int silu, float* workspace, void* stream);
+int td_groupnorm_workspace_floats(void);
+/* p[rows,cols] (bf16) = softmax(scale * s[rows,cols]) (fp32 in). */
+int td_softmax_rows_f32_bf16(const float* s, void* p, int rows, int cols, float scale, void* stream);
 
 /* ---- Qwen2-VL text decoder: hidden states at `model.norm` + KV-cached decoding -------------------------
  * Replaces the vLLM fork's model runner behind `self.mllama.generate(inputs, sampling_params)` with

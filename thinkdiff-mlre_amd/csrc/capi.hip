@@ -56,6 +56,24 @@ int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* 
   return td_gemm_launch(p, (hipStream_t)stream);
 }
 
+int td_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, const void* res, void* y,
+                         int H, int W, int Cin, int Cout, int upsample2x, void* stream) {
+  TdGemmParams p;
+  p.A = (const bf16_t*)x; p.lda = Cin; p.W = (const bf16_t*)w; p.bias = (const bf16_t*)bias;
+  p.C = (bf16_t*)y; p.ldc = Cout; p.res = (const bf16_t*)res; p.ldr = Cout;
+  p.M = H * W; p.N = Cout; p.K = 9 * Cin;
+  p.conv_H = H; p.conv_W = W; p.conv_Cin = Cin; p.conv_up = upsample2x ? 1 : 0;
+  return td_gemm_launch(p, (hipStream_t)stream);
+}
+
+int td_linear_f32out_bf16(const void* x, int64_t ldx, const void* w, const void* bias, float* y, int64_t ldy,
+                          int M, int N, int K, void* stream) {
+  TdGemmParams p;
+  p.A = (const bf16_t*)x; p.lda = (int)ldx; p.W = (const bf16_t*)w; p.bias = (const bf16_t*)bias;
+  p.C = (bf16_t*)y; p.ldc = (int)ldy; p.M = M; p.N = N; p.K = K; p.out_f32 = 1; p.cfg = (N <= 64) ? 1 : (M <= 32 ? 2 : 0);
+  return td_gemm_launch(p, (hipStream_t)stream);
+}
+
 static int g_attn_variant = 0;
 int td_attention_set_variant(int variant) {
   const int prev = g_attn_variant;
@@ -145,6 +163,18 @@ int td_silu_mul_bf16(const void* gate_up, void* out, int rows, int I, void* stre
 }
 int td_mrope_table(const int* pos3n, int n, const int* sections3, float theta, int round_bf16, float* cos, float* sin, void* stream) {
   return td_mrope_table_launch(pos3n, n, sections3, theta, round_bf16, cos, sin, (hipStream_t)stream);
+}
+
+int td_conv3x3_pack_weight(const void* w_oihw, void* w_packed, int Cout, int Cin, int Cout_pad, int Cin_pad, void* stream) {
+  return td_conv_pack_launch((const bf16_t*)w_oihw, (bf16_t*)w_packed, Cout, Cin, Cout_pad, Cin_pad, (hipStream_t)stream);
+}
+int td_groupnorm_nhwc_bf16(const void* x, void* y, int P, int C, int groups, float eps, const void* gamma,
+                           const void* beta, int silu, float* workspace, void* stream) {
+  return td_groupnorm_nhwc_launch((const bf16_t*)x, (bf16_t*)y, P, C, groups, eps, (const bf16_t*)gamma, (const bf16_t*)beta, silu, workspace, (hipStream_t)stream);
+}
+int td_groupnorm_workspace_floats(void) { return 1024 * 64 * 2 + 256; }
+int td_softmax_rows_f32_bf16(const float* s, void* p, int rows, int cols, float scale, void* stream) {
+  return td_softmax_rows_launch(s, (bf16_t*)p, rows, cols, scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -86,6 +86,15 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
         }
       }
     }
+    if (pp.out_f32) {   // raw fp32 rows (attention scores of the VAE mid block): no bf16 rounding of the sum
+      float* fp = (float*)Cout + (size_t)m * ldo + ncol;
+#pragma unroll
+      for (int c = 0; c < NV; c += 4) {
+        const f32x4_t o4 = {acc[c / 4][i][0] + bias[c], acc[c / 4][i][1] + bias[c + 1], acc[c / 4][i][2] + bias[c + 2], acc[c / 4][i][3] + bias[c + 3]};
+        if (mok && nbeg + c + 4 <= pp.N) *(f32x4_t*)(fp + c) = o4;
+      }
+      continue;
+    }
     bf16_t* cp = Cout + (size_t)m * ldo + ncol;
     if constexpr (NV % 8 == 0) {
 #pragma unroll
@@ -108,7 +117,7 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
 
 }  // namespace
 
-template <int WM, int WN, int VARIANT = 2>
+template <int WM, int WN, int VARIANT = 2, bool CONV = false>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   constexpr int BM = 32 * WM, BN = 64 * WN;
@@ -153,7 +162,8 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
-  const unsigned bytesA = (unsigned)(((long long)(pv.M - 1) * p.lda + p.K) * 2);
+  const unsigned bytesA = CONV ? (unsigned)((long long)(p.conv_H >> p.conv_up) * (p.conv_W >> p.conv_up) * p.conv_Cin * 2)
+                                : (unsigned)(((long long)(pv.M - 1) * p.lda + p.K) * 2);
   const unsigned bytesW = (unsigned)((long long)p.N * p.K * 2);
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Aptr, 0, bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wptr, 0, bytesW, 0x00020000);
@@ -188,12 +198,40 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     voffS[SA + s] = (unsigned)n * (unsigned)p.K * 2u + schunk;
     ldsS[SA + s] = g * 1024;
   }
+  // Implicit-GEMM 3x3 convolution (CONV): A is an NHWC image [Hin*Win, Cin]; k-tile kt covers tap kt / (Cin/64)
+  // and input channels 64*(kt % (Cin/64)).  A row (= output pixel) reads input pixel (y+dy, x+dx) -- or its
+  // nearest-neighbour parent when the conv follows a 2x upsample -- and taps outside the image are sent past the
+  // descriptor range, so the zero padding costs nothing.
+  int cy[SA], cx[SA];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int s = 0; s < SA; ++s) {
+      int g2 = wid + 8 * s;
+      if (GA % 8 != 0 && g2 >= GA) g2 %= GA;
+      const int pix = m0 + g2 * 8 + srow;
+      cy[s] = pix < pv.M ? pix / p.conv_W : -4;   // rows past M never validate
+      cx[s] = pix - (pix / p.conv_W) * p.conv_W;
+    }
+  }
+  auto conv_voff = [&](int s, int kt) -> unsigned {
+    const int cpt = p.conv_Cin >> 6;
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
+    const int dy = (tap * 11 >> 5) - 1, dx = tap - (tap * 11 >> 5) * 3 - 1;
+    const int yy = cy[s] + dy, xx = cx[s] + dx;
+    const bool ok = (unsigned)yy < (unsigned)p.conv_H && (unsigned)xx < (unsigned)p.conv_W;
+    const int sy = yy >> p.conv_up, sx = xx >> p.conv_up, win = p.conv_W >> p.conv_up;
+    const unsigned off = ((unsigned)(sy * win + sx) * (unsigned)p.conv_Cin + (unsigned)c0) * 2u + schunk;
+    return ok ? off : 0xFFFFFF00u;
+  };
   // LDS: [A buf 0 | A buf 1 | W buf 0 | W buf 1 | W buf 2]; the third W buffer exists for VARIANT 2 only
   constexpr int W_REGION = 2 * A_BYTES;
   auto stage_one = [&](int s, int abuf, int wbuf, int kt) {
-    if (s < SA)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)(smem + abuf * A_BYTES + ldsS[s]), 16, voffS[s], kt * (BK * 2), 0, 0);
-    else
+    if (s < SA) {
+      if constexpr (CONV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)(smem + abuf * A_BYTES + ldsS[s]), 16, conv_voff(s, kt), 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (TD_LDS void*)(smem + abuf * A_BYTES + ldsS[s]), 16, voffS[s], kt * (BK * 2), 0, 0);
+    } else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (TD_LDS void*)(smem + W_REGION + wbuf * W_BYTES + ldsS[s]), 16, voffS[s], kt * (BK * 2), 0, 0);
   };
 
@@ -348,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 
 namespace {
 
-template <int WM, int WN, int VARIANT = 2>
+template <int WM, int WN, int VARIANT = 2, bool CONV = false>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int LDS = (2 * BM + (VARIANT == 2 ? 3 : 2) * BN) * ROW_BYTES;
@@ -359,12 +397,12 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   static bool attr_set = false;
   if (!attr_set) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, VARIANT>,
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, VARIANT>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -387,7 +425,7 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "td_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   TD_CHECK_ARG(p.K % BK == 0, "td_gemm: K=%d must be a multiple of %d", p.K, BK);
   TD_CHECK_ARG(p.N % 8 == 0, "td_gemm: N=%d must be a multiple of 8", p.N);
-  TD_CHECK_ARG(p.lda >= p.K && p.ldc >= (p.C2 ? p.n_split : p.N), "td_gemm: bad leading dimensions");
+  TD_CHECK_ARG((p.conv_H > 0 || p.lda >= p.K) && p.ldc >= (p.C2 ? p.n_split : p.N), "td_gemm: bad leading dimensions");
   TD_CHECK_ARG(((long long)(p.M + 255) * p.lda + p.K) * 2 < (1ll << 32) && (long long)(p.N + 255) * p.K * 2 < (1ll << 32),
                "td_gemm: operand exceeds the 4 GiB buffer-descriptor range");
   TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C) % 16 == 0 && p.lda % 8 == 0 && p.ldc % 8 == 0,
@@ -397,6 +435,12 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   if (p.g_M > 0) {
     TD_CHECK_ARG(p.g_A && p.g_W && p.g_C && !p.C2, "td_gemm: grouped launch needs A/W/C of the second problem and no split output");
     TD_CHECK_ARG(((uintptr_t)p.g_A | (uintptr_t)p.g_W | (uintptr_t)p.g_C) % 16 == 0, "td_gemm: grouped pointers must be 16-byte aligned");
+  }
+  if (p.conv_H > 0) {
+    TD_CHECK_ARG(p.conv_Cin % 64 == 0 && p.K == 9 * p.conv_Cin && p.M == p.conv_H * p.conv_W && p.g_M == 0 && !p.C2,
+                 "td_gemm(conv): need Cin %% 64 == 0, K == 9 Cin, M == H W (got Cin=%d K=%d M=%d H=%d W=%d)", p.conv_Cin, p.K, p.M, p.conv_H, p.conv_W);
+    TD_CHECK_ARG(p.conv_up == 0 || (p.conv_H % 2 == 0 && p.conv_W % 2 == 0), "td_gemm(conv): upsampled output dims must be even");
+    return p.N <= 64 ? launch_cfg<8, 1, 2, true>(p, stream) : launch_cfg<8, 4, 2, true>(p, stream);
   }
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K);
   switch (cfg) {   // 0-3: shipped pipeline (VARIANT 2); 1x / 3x: earlier loop structures kept for in-process A/B

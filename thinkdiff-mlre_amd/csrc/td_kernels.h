@@ -23,6 +23,10 @@ struct TdGemmParams {
   const bf16_t* g_gate = nullptr; const bf16_t* g_res = nullptr; bf16_t* g_C = nullptr;
   int g_M = 0;
   int cfg = -1;                  // tile config override (-1: auto), see td_gemm_config_id
+  int out_f32 = 0;               // C is float* (ldc in floats): acc + bias stored unrounded, no act/gate/res
+  // implicit-GEMM 3x3 convolution over an NHWC image (conv_H > 0): A = input [Hin*Win, Cin], W = [N, 9*Cin]
+  // (k = tap*Cin + c, tap = ky*3+kx), M = conv_H*conv_W output pixels; conv_up = 1 fuses a nearest 2x upsample
+  int conv_H = 0, conv_W = 0, conv_Cin = 0, conv_up = 0;
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
 };
 
@@ -85,3 +89,12 @@ int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t
 int td_embed_gather_launch(const int* ids, const bf16_t* table, bf16_t* out, int n, int D, int vocab, hipStream_t stream);
 int td_silu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, hipStream_t stream);
 int td_mrope_table_launch(const int* pos, int n, const int* sections, float theta, int round_bf16, float* cosT, float* sinT, hipStream_t stream);
+
+// VAE decoder kernels (vae_kernels.hip); groupnorm workspace: 1024*64*2 + 256 floats
+int td_groupnorm_nhwc_launch(const bf16_t* x, bf16_t* y, int P, int C, int G, float eps, const bf16_t* gamma, const bf16_t* beta,
+                             int silu, float* workspace, hipStream_t stream);
+int td_softmax_rows_launch(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t stream);
+int td_conv_pack_launch(const bf16_t* w, bf16_t* out, int Cout, int Cin, int Cout_pad, int Cin_pad, hipStream_t stream);
+int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float mul, float add, hipStream_t stream);
+int td_image_finalize_launch(const bf16_t* x, int P, int Cpad, unsigned char* u8, bf16_t* chw, hipStream_t stream);
+extern "C" int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float mean, void* stream);

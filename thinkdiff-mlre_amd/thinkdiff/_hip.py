@@ -63,6 +63,18 @@ def _declare(L):
         "td_flux_trace_begin": [vp, i32],
         "td_flux_trace_end": [vp, vp, vp, vp, vp],
         "td_attention_set_variant": [i32],
+        "td_vae_create": [vp, i32, i32, vp],
+        "td_vae_num_params": [vp],
+        "td_vae_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
+        "td_vae_load_param": [vp, ctypes.c_char_p, vp, i64, vp],
+        "td_vae_init_random": [vp, ctypes.c_uint64, f32, vp],
+        "td_vae_decode": [vp, vp, i32, i32, f32, f32, vp, vp, vp],
+        "td_conv3x3_nhwc_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+        "td_conv3x3_pack_weight": [vp, vp, i32, i32, i32, i32, vp],
+        "td_linear_f32out_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp],
+        "td_groupnorm_nhwc_bf16": [vp, vp, i32, i32, i32, f32, vp, vp, i32, vp, vp],
+        "td_groupnorm_workspace_floats": [],
+        "td_softmax_rows_f32_bf16": [vp, vp, i32, i32, f32, vp],
         "td_qwen2_create": [vp, i32, vp],
         "td_qwen2_num_params": [vp],
         "td_qwen2_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
@@ -80,6 +92,8 @@ def _declare(L):
         fn.restype = ctypes.c_int
     L.td_flux_destroy.argtypes = [vp]
     L.td_flux_destroy.restype = None
+    L.td_vae_destroy.argtypes = [vp]
+    L.td_vae_destroy.restype = None
     L.td_qwen2_destroy.argtypes = [vp]
     L.td_qwen2_destroy.restype = None
     L.td_flux_param_elems.argtypes = [vp]
@@ -253,3 +267,33 @@ class TdQwen2Config(ctypes.Structure):
                 ("num_kv_heads", ctypes.c_int), ("head_dim", ctypes.c_int), ("intermediate", ctypes.c_int),
                 ("vocab", ctypes.c_int), ("tie_embeddings", ctypes.c_int), ("mrope_section", ctypes.c_int * 3),
                 ("rms_eps", ctypes.c_float), ("rope_theta", ctypes.c_float)]
+
+
+class TdVaeConfig(ctypes.Structure):
+    """Mirror of `struct TdVaeConfig` (include/thinkdiff_hip.h)."""
+    _fields_ = [("latent_channels", ctypes.c_int), ("out_channels", ctypes.c_int), ("num_blocks", ctypes.c_int),
+                ("block_out_channels", ctypes.c_int * 4), ("layers_per_block", ctypes.c_int), ("norm_groups", ctypes.c_int)]
+
+
+def conv3x3_nhwc(x, w_packed, bias, H, W, Cout, res=None, upsample2x=False):
+    """x [Hin*Win, Cin] bf16 NHWC, w_packed [Cout, 9*Cin] -> [H*W, Cout]"""
+    Cin = x.shape[1]
+    y = torch.empty(H * W, Cout, dtype=torch.bfloat16, device=x.device)
+    check(lib().td_conv3x3_nhwc_bf16(ptr(x), ptr(w_packed), ptr(bias), ptr(res), ptr(y), H, W, Cin, Cout, int(upsample2x), stream_ptr()))
+    return y
+
+
+def conv3x3_pack_weight(w_oihw, Cout_pad=None, Cin_pad=None):
+    Cout, Cin = w_oihw.shape[:2]
+    Cout_pad, Cin_pad = Cout_pad or Cout, Cin_pad or Cin
+    out = torch.empty(Cout_pad, 9 * Cin_pad, dtype=torch.bfloat16, device=w_oihw.device)
+    check(lib().td_conv3x3_pack_weight(ptr(w_oihw.contiguous()), ptr(out), Cout, Cin, Cout_pad, Cin_pad, stream_ptr()))
+    return out
+
+
+def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-6, silu=False):
+    P, C = x.shape
+    ws = torch.empty(lib().td_groupnorm_workspace_floats(), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(lib().td_groupnorm_nhwc_bf16(ptr(x), ptr(y), P, C, groups, float(eps), ptr(gamma), ptr(beta), int(silu), ptr(ws), stream_ptr()))
+    return y

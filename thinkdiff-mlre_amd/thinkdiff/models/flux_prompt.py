@@ -63,12 +63,18 @@ class FluxPipelineRewritePrompt:
             raise FileNotFoundError(
                 f"{pretrained_model_name_or_path!r} is not a local directory; this build loads FLUX weights from "
                 "disk only (or use FluxPipelineRewritePrompt.from_random for synthetic weights)")
-        return cls(transformer=FluxTransformer2DModel.from_pretrained(pretrained_model_name_or_path, **kw))
+        from .flux_vae import AutoencoderKLDecoder
+        vae = None
+        if os.path.isdir(os.path.join(pretrained_model_name_or_path, "vae")):
+            vae = AutoencoderKLDecoder.from_pretrained(pretrained_model_name_or_path)
+        return cls(transformer=FluxTransformer2DModel.from_pretrained(pretrained_model_name_or_path, **kw), vae=vae)
 
     @classmethod
-    def from_random(cls, config: Optional[FluxTransformerConfig] = None, seed: int = 0, **kw):
+    def from_random(cls, config: Optional[FluxTransformerConfig] = None, seed: int = 0, with_vae: bool = True, **kw):
         """Synthetic FLUX.1-dev-shaped checkpoint created on the device (benchmarks, plumbing tests)."""
-        return cls(transformer=FluxTransformer2DModel(config, **kw).init_random(seed))
+        from .flux_vae import AutoencoderKLDecoder
+        vae = AutoencoderKLDecoder().init_random(seed + 1) if with_vae else None
+        return cls(transformer=FluxTransformer2DModel(config, **kw).init_random(seed), vae=vae)
 
     def to(self, *_a, **_k):
         return self  # the engine lives on the GPU it was created on
@@ -173,17 +179,15 @@ class FluxPipelineRewritePrompt:
             tr.denoise(x, sig)
             if output_type == "latent":      # diffusers: packed latents, no unpack
                 outs.append(x)
-            else:                            # _unpack_latents + (z / scaling_factor + shift_factor)
+            elif output_type == "vae_input":  # _unpack_latents + (z / scaling_factor + shift_factor), no decode
                 outs.append(_hip.flux_unpack_latents(x, tr.config.in_channels // 4, h, w,
                                                      1.0 / self.vae_scaling_factor, self.vae_shift_factor))
-        z = torch.stack(outs)
-        if output_type in ("latent", "vae_input"):
-            images = z
-        elif self.vae is None:
-            raise _hip.ThinkDiffHipError("no VAE loaded: call with output_type='latent' (packed latents) or "
-                                         "'vae_input' (unpacked, scaled decoder input)")
-        else:
-            images = self.vae.decode(z, output_type=output_type)
+            elif self.vae is None:
+                raise _hip.ThinkDiffHipError("no VAE loaded: call with output_type='latent' (packed latents) or "
+                                             "'vae_input' (unpacked, scaled decoder input)")
+            else:                             # unpack + affine + vae.decode + postprocess, all in td_vae_decode
+                outs.append(self.vae.decode_packed(x, h, w, output_type=output_type))
+        images = outs if output_type == "pil" else torch.stack(outs)
         if not return_dict:
             return (images,)
         return SimpleNamespace(images=images)
