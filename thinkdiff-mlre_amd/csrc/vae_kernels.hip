@@ -58,19 +58,25 @@ __global__ __launch_bounds__(256) void td_gn_partial_kernel(const bf16_t* x, int
   }
 }
 
-// pass 2: stats[g] = (mean, rstd), accumulated in double over the block partials
-__global__ void td_gn_finalize_kernel(const float* partial, int nblocks, int G, double count, float eps, float* stats) {
-  const int g = threadIdx.x;
-  if (g >= G) return;
+// pass 2: stats[g] = (mean, rstd); one wave per group sums the block partials in double
+__global__ __launch_bounds__(64) void td_gn_finalize_kernel(const float* partial, int nblocks, int G, double count, float eps, float* stats) {
+  const int g = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
+  for (int b = lane; b < nblocks; b += 64) {
     s += partial[((size_t)b * G + g) * 2];
     q += partial[((size_t)b * G + g) * 2 + 1];
   }
-  const double mean = s / count;
-  const double var = fmax(q / count - mean * mean, 0.0);
-  stats[2 * g] = (float)mean;
-  stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) {
+    const double mean = s / count;
+    const double var = fmax(q / count - mean * mean, 0.0);
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // pass 3: y = bf16((x - mean) rstd gamma + beta), optionally y = bf16(silu(y))
@@ -103,7 +109,7 @@ int td_groupnorm_nhwc_launch(const bf16_t* x, bf16_t* y, int P, int C, int G, fl
   float* partial = workspace;
   float* stats = workspace + (size_t)1024 * 64 * 2;
   hipLaunchKernelGGL(td_gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, x, P, C, G, ppb, partial);
-  hipLaunchKernelGGL(td_gn_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, nblocks, G, (double)P * (C / G), eps, stats);
+  hipLaunchKernelGGL(td_gn_finalize_kernel, dim3(G), dim3(64), 0, stream, partial, nblocks, G, (double)P * (C / G), eps, stats);
   const long long n8 = (long long)P * C / 8;
   hipLaunchKernelGGL(td_gn_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, x, y, n8, C, G, stats, gamma, beta, silu);
   TD_CHECK_LAUNCH();
