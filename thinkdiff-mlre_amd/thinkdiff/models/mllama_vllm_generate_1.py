@@ -1,0 +1,82 @@
+"""Precompute model (BASELINE config 4): Qwen2-VL generate + hidden states for a whole loader batch.
+
+Mirror of reference thinkdiff/models/mllama_vllm_generate_1.py `MllamaVllmGenerate_1` (:364-718): `forward(samples)`
+(:625-641) -> `forward_inner` (:493-623) returns
+  {"generated_text": [str], "generated_token": {"input_prompt", "input_prompt_token_ids", "output_text",
+   "output_token_ids"}, "generated_embed": {"model.norm": {"output_embed": [Tensor[n_gen,D]], "input_embed":
+   [Tensor[n_prompt,D]]}}}.
+The vLLM engine is replaced by `Qwen2VLTextEngine` (HIP).  Tokenisation / chat templating / the vision tower need
+assets or rows that are not built: `request_builder(sample_i) -> {"prompt", "prompt_token_ids",
+optional "inputs_embeds", "position_ids"}` supplies them; the default builder handles text-only requests with
+a caller-provided tokenizer.
+"""
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .. import _hip
+from ..common.registry import registry
+from .base_model import BaseModel
+from .qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
+
+
+@registry.register_model("mllama-vllm-generate-1")
+class MllamaVllmGenerate_1(BaseModel):
+    PRETRAINED_MODEL_CONFIG_DICT = {"pretrain_mllama_vllm_generate_1": "configs/models/mllama_vllm_generate_1.yaml"}
+
+    def __init__(self, text_config: Optional[Qwen2VLTextConfig] = None, vllm_config: Optional[dict] = None,
+                 text_input_key: Optional[str] = "answers", device="cuda", tokenizer=None,
+                 request_builder: Optional[Callable[[dict, int], dict]] = None):
+        vc = dict(vllm_config or {})
+        self.config = SimpleNamespace(vllm_config=vc, text_input_key=text_input_key)
+        self._device = torch.device(device)
+        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device)
+        self.mllama_sampling_params = SamplingParams(
+            temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 256),
+            min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False))
+        self.mllama_tokenizer = tokenizer
+        self.request_builder = request_builder
+        self.eos_token_id = vc.get("eos_token_id", None)
+
+    @classmethod
+    def from_config(cls, cfg):
+        vc = cfg.get("vllm_config", {})
+        vc = vc.to_dict() if hasattr(vc, "to_dict") else dict(vc)
+        return cls(vllm_config=vc, text_input_key=cfg.get("text_input_key", "answers"), device=cfg.get("device", "cuda"))
+
+    def _request(self, samples: dict, i: int) -> dict:
+        if self.request_builder is not None:
+            return self.request_builder(samples, i)
+        texts = samples["answers"] if self.config.text_input_key is None else samples[self.config.text_input_key]
+        if self.mllama_tokenizer is None:
+            raise _hip.ThinkDiffHipError("MllamaVllmGenerate_1: supply `request_builder` (token ids / vision embeddings) or a tokenizer")
+        prompt = texts[i]
+        return {"prompt": prompt, "prompt_token_ids": self.mllama_tokenizer.encode(prompt, add_special_tokens=False)}
+
+    @torch.no_grad()
+    def forward_inner(self, mllama_inputs: dict, generator=None) -> Dict:
+        n = len(mllama_inputs["images"]) if "images" in mllama_inputs else len(mllama_inputs["answers"])
+        layer = self.config.vllm_config.get("embedding_layer_name", "model.norm")
+        tok = {"input_prompt": [], "input_prompt_token_ids": [], "output_text": [], "output_token_ids": []}
+        out_embed, in_embed, texts = [], [], []
+        for i in range(n):
+            r = self._request(mllama_inputs, i)
+            o = self.mllama.generate(r["prompt_token_ids"], self.mllama_sampling_params, position_ids=r.get("position_ids"),
+                                     inputs_embeds=r.get("inputs_embeds"), eos_token_id=self.eos_token_id, generator=generator)
+            text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
+            tok["input_prompt"].append(r.get("prompt", ""))
+            tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
+            tok["output_text"].append(text)
+            tok["output_token_ids"].append(tuple(o["token_ids"]))
+            texts.append(text)
+            out_embed.append(o["hidden_states"])
+            in_embed.append(o["prompt_hidden_states"])
+        return {"generated_text": texts, "generated_token": tok,
+                "generated_embed": {layer: {"output_embed": out_embed, "input_embed": in_embed}}}
+
+    def forward(self, samples, reduction="mean"):
+        inputs = {k: v for k, v in samples.items() if k not in ("epoch", "num_iters_per_epoch", "iters")}
+        return self.forward_inner(mllama_inputs=inputs)
+
+    __call__ = forward

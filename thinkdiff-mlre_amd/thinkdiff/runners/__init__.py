@@ -32,4 +32,6 @@ class RunnerClipT5(RunnerBase):
     pass
 
 
-__all__ = ["RunnerBase", "RunnerClipT5", "dp_inference"]
+from .runner_process_data import RunnerProcessData  # noqa: E402
+
+__all__ = ["RunnerBase", "RunnerClipT5", "RunnerProcessData", "dp_inference"]

@@ -28,3 +28,6 @@ def setup_task(cfg):
     cls = registry.get_task_class(task_name)
     assert cls is not None, f"Task {task_name} not properly registered."
     return cls.setup_task(cfg=cfg)
+
+
+from .image_text_process_data import ImageTextProcessDataTask  # noqa: E402,F401
