@@ -1,0 +1,62 @@
+"""Where the not-yet-built upstream stages of the ThinkDiff-CLIP driver come from:
+the EVA-ViT-g vision tower + Blip2Processor and the CLIP-L / T5-XXL text encoders.
+
+* `run.local_weights.<name>` pointing at a local directory -> the Hugging Face module is loaded from disk and run
+  on the GPU through PyTorch-ROCm (interim: these stages are < 1 % of an image's FLOPs and are "next" rows);
+* `run.synthetic: true` -> seeded synthetic stand-ins with the right shapes, so the whole driver (config surface,
+  naming rules, aligner, FLUX, VAE, PNG writing) can be exercised without any asset.  Hub ids are never fetched.
+"""
+import hashlib
+
+import torch
+
+
+def _seed_from(*parts) -> int:
+    return int(hashlib.sha256("|".join(map(str, parts)).encode()).hexdigest()[:8], 16)
+
+
+class SyntheticVisionTower:
+    """pixel_values [B,3,224,224] -> [B,257,1408], deterministic in the pixels (seeded by their checksum)."""
+
+    def __call__(self, pixel_values):
+        outs = []
+        for b in range(pixel_values.shape[0]):
+            g = torch.Generator().manual_seed(_seed_from("vision", float(pixel_values[b].float().sum())))
+            outs.append(torch.randn(257, 1408, generator=g))
+        return torch.stack(outs).to(pixel_values.device, torch.bfloat16)
+
+
+class SyntheticImageProcessor:
+    """Blip2Processor stand-in: resize to 224 (bicubic), rescale, CLIP mean/std -> {'pixel_values': [1,3,224,224]}."""
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+
+    def __call__(self, image, text=None, return_tensors="pt"):
+        import numpy as np
+        from PIL import Image
+        arr = np.asarray(image.convert("RGB").resize((224, 224), Image.BICUBIC), dtype=np.float32) / 255.0
+        t = (torch.from_numpy(arr).permute(2, 0, 1) - torch.tensor(self.mean)[:, None, None]) / torch.tensor(self.std)[:, None, None]
+        return {"pixel_values": t[None]}
+
+
+class SyntheticTextEncoders:
+    """encode_prompt stand-in: T5 [1,max_len,4096] and CLIP pooled [1,768], deterministic in the prompt text."""
+
+    def t5(self, prompt: str, max_sequence_length: int, device):
+        g = torch.Generator().manual_seed(_seed_from("t5", prompt))
+        return (0.1 * torch.randn(1, max_sequence_length, 4096, generator=g)).to(device, torch.bfloat16)
+
+    def clip_pooled(self, prompt: str, device):
+        g = torch.Generator().manual_seed(_seed_from("clip", prompt))
+        return torch.randn(1, 768, generator=g).to(device, torch.bfloat16)
+
+
+def load_vision(run_cfg, device):
+    lw = run_cfg.get("local_weights", None) or {}
+    if lw.get("blip2", None):
+        from transformers import Blip2Processor, Blip2VisionModel
+        proc = Blip2Processor.from_pretrained(lw["blip2"], local_files_only=True)
+        tower = Blip2VisionModel.from_pretrained(lw["blip2"], local_files_only=True, torch_dtype=torch.bfloat16).to(device).eval()
+        return proc, (lambda pv: tower(pixel_values=pv.to(device, torch.bfloat16))[0])
+    if run_cfg.get("synthetic", False):
+        return SyntheticImageProcessor(), SyntheticVisionTower()
+    raise FileNotFoundError("no vision tower: set run.local_weights.blip2 to a local checkpoint directory or run.synthetic: true")
