@@ -41,13 +41,13 @@ struct ProbView {
   const bf16_t* bias; const bf16_t* gate; const bf16_t* res; bf16_t* C; int M;
 };
 
-template <int WM, int WN, int ACT>
+template <int WM, int WN, int ACT, int MODE>   // MODE 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
 __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second) {
   constexpr int NV = 4 * WN;
   bf16_t* Cout = second ? pp.C2 : p.C;
   const int ldo = second ? pp.ldc2 : pp.ldc;
   const int ncol = second ? nbeg - pp.n_split : nbeg;
-  const bool use_gate = p.gate != nullptr, use_res = p.res != nullptr;
+  const bool use_gate = p.gate != nullptr, use_res = p.res != nullptr, has_bias = p.bias != nullptr;
 
   float bias[NV], gate[NV];
 #pragma unroll
@@ -69,20 +69,42 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[j][i][r];
+    // Rounding points of the bf16 torch graph: the Linear output rounds before any following op, and so does every
+    // following op; when nothing follows, the final pack is that rounding.  The stage selection is block-uniform
+    // and sits OUTSIDE the per-value loops (a per-value runtime select tripled the epilogue's VALU count, and the
+    // epilogue is dead time for the matrix pipe at one workgroup per CU).
+    auto round_all = [&]() {
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      float y = rbf(v[c] + bias[c]);
-      if constexpr (ACT != TD_ACT_NONE) y = rbf(apply_act<ACT>(y));
-      if (use_gate) y = rbf(y * gate[c]);
-      v[c] = y;
+      for (int c = 0; c < NV; c += 2) {
+        const unsigned u = pack_bf2(v[c], v[c + 1]);
+        v[c] = bf_lo(u);
+        v[c + 1] = bf_hi(u);
+      }
+    };
+    if (has_bias) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) v[c] += bias[c];
     }
-    if (use_res && mok) {
-      const bf16_t* rp = p.res + (size_t)m * pp.ldr + nbeg;
+    if constexpr (ACT != TD_ACT_NONE) {
+      round_all();
 #pragma unroll
-      for (int c = 0; c < NV; c += 4) {
-        if (nbeg + c + 4 <= pp.N) {
-          const u32x2_t rv = *(const u32x2_t*)(rp + c);
-          v[c] += bf_lo(rv[0]); v[c + 1] += bf_hi(rv[0]); v[c + 2] += bf_lo(rv[1]); v[c + 3] += bf_hi(rv[1]);
+      for (int c = 0; c < NV; ++c) v[c] = apply_act<ACT>(v[c]);
+    }
+    if constexpr (MODE == 1) {
+      round_all();
+#pragma unroll
+      for (int c = 0; c < NV; ++c) v[c] *= gate[c];
+    }
+    if constexpr (MODE != 0) {
+      if (use_res && mok) {
+        round_all();
+        const bf16_t* rp = p.res + (size_t)m * pp.ldr + nbeg;
+#pragma unroll
+        for (int c = 0; c < NV; c += 4) {
+          if (nbeg + c + 4 <= pp.N) {
+            const u32x2_t rv = *(const u32x2_t*)(rp + c);
+            v[c] += bf_lo(rv[0]); v[c + 1] += bf_hi(rv[0]); v[c + 2] += bf_lo(rv[1]); v[c + 3] += bf_hi(rv[1]);
+          }
         }
       }
     }
@@ -375,11 +397,15 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   const int mbeg = m0 + wr * 16 * WM + frow;
   // one instantiation per activation keeps every acc[][] index static (runtime-indexed
   // accumulators would be demoted to scratch)
-  switch (act) {
-    case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH>(p, pv, acc, mbeg, nbeg, second); break;
-    case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF>(p, pv, acc, mbeg, nbeg, second); break;
-    case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU>(p, pv, acc, mbeg, nbeg, second); break;
-    default: epilogue<WM, WN, TD_ACT_NONE>(p, pv, acc, mbeg, nbeg, second); break;
+  // (an activation followed by a gate / residual does not occur on this path: act wins, as before the split)
+  const int mode = act != TD_ACT_NONE ? 0 : (pv.gate ? 1 : (pv.res ? 2 : 0));
+  if (mode == 1) epilogue<WM, WN, TD_ACT_NONE, 1>(p, pv, acc, mbeg, nbeg, second);
+  else if (mode == 2) epilogue<WM, WN, TD_ACT_NONE, 2>(p, pv, acc, mbeg, nbeg, second);
+  else switch (act) {
+    case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH, 0>(p, pv, acc, mbeg, nbeg, second); break;
+    case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF, 0>(p, pv, acc, mbeg, nbeg, second); break;
+    case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU, 0>(p, pv, acc, mbeg, nbeg, second); break;
+    default: epilogue<WM, WN, TD_ACT_NONE, 0>(p, pv, acc, mbeg, nbeg, second); break;
   }
 #endif
 }
