@@ -22,7 +22,7 @@ extern "C" {
 
 enum { TD_OK = 0, TD_ERR_INVALID = 2, TD_ERR_HIP = 3 };
 /* activation codes for td_linear_bf16 */
-enum { TD_ACT_ID_NONE = 0, TD_ACT_ID_GELU_TANH = 1, TD_ACT_ID_GELU_ERF = 2, TD_ACT_ID_SILU = 3 };
+enum { TD_ACT_ID_NONE = 0, TD_ACT_ID_GELU_TANH = 1, TD_ACT_ID_GELU_ERF = 2, TD_ACT_ID_SILU = 3, TD_ACT_ID_QUICK_GELU = 4 };
 
 const char* td_last_error(void);
 int td_abi_version(void);
@@ -175,6 +175,19 @@ int td_flux_trace_begin(td_flux* f, int max_launches);
 int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, double* flops);
 /* n Euler steps in place; sigmas: n+1 host floats */
 int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream);
+
+/* ---- building blocks of the text encoders (T5-XXL, CLIP-L) feeding encode_prompt
+ * (thinkdiff/models/flux_prompt.py:88-104 -> [ext] FluxPipeline._get_t5_prompt_embeds / _get_clip_prompt_embeds) ---- */
+/* y = norm(x) for any D % 8 == 0: rms = 0 nn.LayerNorm(w, b, eps), rms = 1 T5LayerNorm(w). */
+int td_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, int rms, float eps,
+                      const void* w, const void* b, void* stream);
+/* out[r,:] = a[r,:] + b[r % b_rows,:]  (token + position embeddings, bias rows). */
+int td_add_rows_bf16(const void* a, const void* b, void* out, int rows, int D, int b_rows, void* stream);
+/* out[m,j] = act(gu[m,j]) * gu[m,I+j]  (T5 gated-GELU / SwiGLU); act = TD_ACT_ID_*. */
+int td_glu_mul_bf16(const void* gate_up, void* out, int rows, int I, int act, void* stream);
+/* td_attention_bf16 with an additive fp32 score bias [Hq,Sq,Skv] (T5 relative position bias), batch 1. */
+int td_attention_bias_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
+                           int Sq, int Skv, int Hq, int Hkv, float scale, int causal, const float* bias, void* stream);
 
 /* ---- FLUX VAE decoder (AutoencoderKL.decode) -------------------------------------------------------------
  * Replaces the tail of the drivers' `diffusion_pipe(...)` call: [ext] diffusers 0.31.0 FluxPipeline

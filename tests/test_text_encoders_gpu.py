@@ -1,0 +1,102 @@
+"""GPU parity of the HIP T5 encoder / CLIP text encoder against the modules the reference's encode_prompt calls:
+transformers T5EncoderModel and CLIPTextModel themselves (tiny random configs, bf16 on CPU).
+
+Tolerance: bf16 pipelines with the same rounding points, different fp32 summation order: relative RMSE <= 2e-2.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def test_t5_encoder_matches_transformers(hip):
+    from transformers import T5Config, T5EncoderModel
+    from thinkdiff.models.text_encoders import HipT5Encoder
+    torch.manual_seed(0)
+    cfg = T5Config(vocab_size=512, d_model=256, d_kv=64, d_ff=512, num_layers=3, num_heads=4, feed_forward_proj="gated-gelu",
+                   relative_attention_num_buckets=32, relative_attention_max_distance=128, dropout_rate=0.0)
+    ref = T5EncoderModel(cfg).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(3.0)           # default init is tiny: make attention / bias matter
+    ref = ref.bfloat16()
+    ids = torch.randint(0, 512, (2, 128))
+    with torch.no_grad():
+        want = ref(input_ids=ids)[0]
+    enc = HipT5Encoder(ref.state_dict(), num_heads=4, d_kv=64)
+    got = enc(ids, output_hidden_states=False)[0]
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (2, 128, 256)
+    e = _rel(got, want)
+    print(f"T5 rel-RMSE {e:.4f}")
+    assert e < 2e-2
+
+
+def test_clip_text_encoder_matches_transformers(hip):
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from thinkdiff.models.text_encoders import HipCLIPTextEncoder
+    torch.manual_seed(1)
+    cfg = CLIPTextConfig(vocab_size=1000, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+                         max_position_embeddings=77, hidden_act="quick_gelu", eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    ref = CLIPTextModel(cfg).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() > 1:
+                p.mul_(2.0)
+    ref = ref.bfloat16()
+    ids = torch.randint(3, 990, (2, 77))
+    ids[0, 20] = 999
+    ids[1, 55] = 999          # "EOS" = the largest id (legacy eos_token_id == 2 -> argmax pooling)
+    with torch.no_grad():
+        out = ref(input_ids=ids)
+    enc = HipCLIPTextEncoder(ref.state_dict(), num_heads=4, eps=cfg.layer_norm_eps, eos_token_id=2)
+    res = enc(ids, output_hidden_states=False)
+    hs, pooled = res.last_hidden_state, res.pooler_output
+    torch.cuda.synchronize()
+    e1, e2 = _rel(hs, out.last_hidden_state), _rel(pooled, out.pooler_output)
+    print(f"CLIP rel-RMSE hidden {e1:.4f} pooled {e2:.4f}")
+    assert e1 < 2e-2 and e2 < 2e-2
+
+
+def test_encode_prompt_runs_hip_encoders(hip, tmp_path):
+    """encode_prompt (flux_prompt.py:37-121) end to end with the HIP encoders loaded from a local diffusers-layout directory."""
+    from safetensors.torch import save_file
+    from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+    from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
+    from thinkdiff.models.text_encoders import HipCLIPTextEncoder, HipT5Encoder
+    torch.manual_seed(2)
+    ccfg = CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                          max_position_embeddings=77, eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    tcfg = T5Config(vocab_size=512, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2, feed_forward_proj="gated-gelu")
+    clip, t5 = CLIPTextModel(ccfg).eval().bfloat16(), T5EncoderModel(tcfg).eval().bfloat16()
+    for sub, m, c in (("text_encoder", clip, ccfg), ("text_encoder_2", t5, tcfg)):
+        (tmp_path / sub).mkdir()
+        sd = {("text_model." + k if sub == "text_encoder" else k): v.contiguous().clone() for k, v in m.state_dict().items()}
+        save_file(sd, str(tmp_path / sub / "model.safetensors"))
+        (tmp_path / sub / "config.json").write_text(c.to_json_string())
+
+    class Tok:            # stand-in tokenizer: deterministic ids, same call signature as the HF tokenizers
+        def __init__(self, vocab):
+            self.vocab = vocab
+        def __call__(self, prompt, padding=None, max_length=77, truncation=True, return_tensors="pt", **kw):
+            g = torch.Generator().manual_seed(len(prompt[0]))
+            return type("E", (), {"input_ids": torch.randint(3, self.vocab - 1, (len(prompt), max_length), generator=g)})()
+
+    pipe = FluxPipelineRewritePrompt(text_encoder=HipCLIPTextEncoder.from_pretrained(str(tmp_path)), tokenizer=Tok(1000),
+                                     text_encoder_2=HipT5Encoder.from_pretrained(str(tmp_path)), tokenizer_2=Tok(512),
+                                     transformer=type("T", (), {"dtype": torch.bfloat16, "device": torch.device("cuda")})())
+    pe, pooled, text_ids = pipe.encode_prompt(["a cat on a mat"], max_sequence_length=64)
+    torch.cuda.synchronize()
+    assert pe.shape == (1, 64, 128) and pooled.shape == (1, 128) and text_ids.shape == (64, 3)
+    ids_c, ids_t = Tok(1000)(["a cat on a mat"], max_length=77).input_ids, Tok(512)(["a cat on a mat"], max_length=64).input_ids
+    with torch.no_grad():
+        assert _rel(pooled, clip(input_ids=ids_c).pooler_output) < 2e-2
+        assert _rel(pe, t5(input_ids=ids_t)[0]) < 2e-2
+    # caller-supplied embeddings bypass the encoders (the ThinkDiff drivers' path)
+    pe2, pooled2, _ = pipe.encode_prompt(None, prompt_embeds=pe, pooled_prompt_embeds=pooled)
+    assert pe2 is pe and pooled2 is pooled

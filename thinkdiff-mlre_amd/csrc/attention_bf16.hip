@@ -416,6 +416,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     }
 
     const int key0 = t * KV_TILE;
+    if (p.bias) {   // additive score bias in the scaled domain: (s + bias/scale) * scale = s*scale + bias
+      const float inv_scale = 1.0f / p.scale;
+      const int qrow = min(q0 + l31, p.Sq - 1);
+      const float* bp = p.bias + ((size_t)head * p.Sq + qrow) * p.Skv + key0 + 4 * h5;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int kbase = key0 + kb * 32 + 8 * g4 + 4 * h5;
+          if (kbase + 4 <= p.Skv) {
+            const f32x4_t bv = *(const f32x4_t*)(bp + kb * 32 + 8 * g4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kb][4 * g4 + r] += bv[r] * inv_scale;
+          }
+        }
+    }
     const bool need_mask = (key0 + KV_TILE > p.Skv) || (CAUSAL && key0 + KV_TILE - 1 > q0 + p.causal_offset);
     if (need_mask) {
 #pragma unroll
@@ -537,7 +553,8 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   }
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
   const int lds = 4 * TILE_BYTES;
-  if (p.variant == 1) {
+  if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
+  if (p.variant == 1 && !p.bias) {
     if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW, false>), grid, dim3(NW * 64), lds, stream, q);
     else hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW, false>), grid, dim3(NW * 64), lds, stream, q);
   } else {

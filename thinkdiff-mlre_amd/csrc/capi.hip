@@ -177,4 +177,24 @@ int td_softmax_rows_f32_bf16(const float* s, void* p, int rows, int cols, float 
   return td_softmax_rows_launch(s, (bf16_t*)p, rows, cols, scale, (hipStream_t)stream);
 }
 
+int td_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, int rms, float eps,
+                      const void* w, const void* b, void* stream) {
+  return td_norm_rows_generic_launch((const bf16_t*)x, (int)ldx, (bf16_t*)y, (int)ldy, rows, D, rms, eps, (const bf16_t*)w, (const bf16_t*)b, (hipStream_t)stream);
+}
+int td_add_rows_bf16(const void* a, const void* b, void* out, int rows, int D, int b_rows, void* stream) {
+  return td_add_rows_launch((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, rows, D, b_rows, (hipStream_t)stream);
+}
+int td_glu_mul_bf16(const void* gate_up, void* out, int rows, int I, int act, void* stream) {
+  return td_glu_mul_launch((const bf16_t*)gate_up, (bf16_t*)out, rows, I, act, (hipStream_t)stream);
+}
+int td_attention_bias_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
+                           int Sq, int Skv, int Hq, int Hkv, float scale, int causal, const float* bias, void* stream) {
+  TdAttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o;
+  p.batch = 1; p.Sq = Sq; p.Skv = Skv; p.Hq = Hq; p.Hkv = Hkv; p.head_dim = 128;
+  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo;
+  p.scale = scale; p.causal = causal; p.causal_offset = Skv - Sq; p.bias = bias;
+  return td_attn_launch(p, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -391,3 +391,96 @@ int td_mrope_table_launch(const int* pos, int n, const int* sections, float thet
   TD_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row normalisation for any D % 8 == 0 (CLIP 768, EVA 1408, Qwen-ViT 1280 ...): LayerNorm with affine weight and
+// bias, or RMSNorm.  One wave per row, two sweeps over the (L2-resident) row.  y = bf16(n * w + b), fp32 statistics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void td_norm_rows_generic_kernel(const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows, int D, int rms,
+                                                                   float eps, const bf16_t* w, const bf16_t* b) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  float s = 0.f, q = 0.f;
+  for (int c = lane * 8; c < D; c += 512) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(xr + c), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s += v[i]; q += v[i] * v[i]; }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  const float mean = rms ? 0.f : s / D;
+  const float var = rms ? q / D : fmaxf(q / D - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  bf16_t* yr = y + (size_t)row * ldy;
+  for (int c = lane * 8; c < D; c += 512) {
+    float v[8], wv[8], bv[8];
+    unpack8(*(const u32x4_t*)(xr + c), v);
+    if (w) unpack8(*(const u32x4_t*)(w + c), wv);
+    if (b) unpack8(*(const u32x4_t*)(b + c), bv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = (v[i] - mean) * rstd;
+      if (rms) { t = rbf(t); if (w) t = t * wv[i]; }      // T5LayerNorm: cast, then weight
+      else { if (w) t = t * wv[i]; if (b) t = t + bv[i]; }  // nn.LayerNorm: one fp32 expression, one rounding
+      v[i] = t;
+    }
+    *(u32x4_t*)(yr + c) = pack8(v);
+  }
+}
+
+int td_norm_rows_generic_launch(const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows, int D, int rms, float eps,
+                                const bf16_t* w, const bf16_t* b, hipStream_t stream) {
+  TD_CHECK_ARG(rows > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "td_layernorm: D and strides must be multiples of 8");
+  hipLaunchKernelGGL(td_norm_rows_generic_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, y, ldy, rows, D, rms, eps, w, b);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// out = a + b (b broadcast over rows when b_rows == 1 .. or cyclic with period b_rows), bf16, fp32 add
+__global__ void td_add_rows_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n8, int row8, int b_rows) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const long long r = idx / row8;
+  const long long bi = (r % b_rows) * row8 + idx % row8;
+  float x[8], y[8];
+  unpack8(((const u32x4_t*)a)[idx], x);
+  unpack8(((const u32x4_t*)b)[bi], y);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] += y[i];
+  ((u32x4_t*)out)[idx] = pack8(x);
+}
+
+int td_add_rows_launch(const bf16_t* a, const bf16_t* b, bf16_t* out, int rows, int D, int b_rows, hipStream_t stream) {
+  TD_CHECK_ARG(rows > 0 && D % 8 == 0 && b_rows > 0, "td_add_rows: bad shape");
+  const long long n8 = (long long)rows * D / 8;
+  hipLaunchKernelGGL(td_add_rows_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, a, b, out, n8, D / 8, b_rows);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// gated unit: out[m, j] = bf16(bf16(act(g[m,j])) * u[m,j]), g | u = the two halves of gu[m, 2I]; act: TdAct code
+__global__ void td_glu_mul_kernel(const bf16_t* gu, bf16_t* out, int rows, int I, int act) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = I / 8;
+  if (idx >= (long long)rows * per_row) return;
+  const int m = (int)(idx / per_row), c = (int)(idx % per_row);
+  float g[8], u[8];
+  unpack8(*(const u32x4_t*)(gu + (size_t)m * 2 * I + c * 8), g);
+  unpack8(*(const u32x4_t*)(gu + (size_t)m * 2 * I + I + c * 8), u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = act == TD_ACT_GELU_TANH ? gelu_tanh_f(g[i]) : act == TD_ACT_GELU_ERF ? gelu_erf_f(g[i]) : silu_f(g[i]);
+    g[i] = rbf(a) * u[i];
+  }
+  *(u32x4_t*)(out + (size_t)m * I + c * 8) = pack8(g);
+}
+
+int td_glu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, int act, hipStream_t stream) {
+  TD_CHECK_ARG(rows > 0 && I % 8 == 0, "td_glu_mul: bad shape");
+  const long long n = (long long)rows * (I / 8);
+  hipLaunchKernelGGL(td_glu_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, out, rows, I, act);
+  TD_CHECK_LAUNCH();
+  return 0;
+}

@@ -30,6 +30,7 @@ __device__ __forceinline__ float apply_act(float x) {
   if constexpr (ACT == TD_ACT_GELU_TANH) return gelu_tanh_f(x);
   else if constexpr (ACT == TD_ACT_GELU_ERF) return gelu_erf_f(x);
   else if constexpr (ACT == TD_ACT_SILU) return silu_f(x);
+  else if constexpr (ACT == TD_ACT_QUICK_GELU) return quick_gelu_f(x);
   else return x;
 }
 
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH, 0>(p, pv, acc, mbeg, nbeg, second); break;
     case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF, 0>(p, pv, acc, mbeg, nbeg, second); break;
     case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU, 0>(p, pv, acc, mbeg, nbeg, second); break;
+    case TD_ACT_QUICK_GELU: epilogue<WM, WN, TD_ACT_QUICK_GELU, 0>(p, pv, acc, mbeg, nbeg, second); break;
     default: epilogue<WM, WN, TD_ACT_NONE, 0>(p, pv, acc, mbeg, nbeg, second); break;
   }
 #endif

@@ -47,6 +47,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }  // x * sigmoid(1.702 x)
 
 // ---- wave reductions (wave64) ------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

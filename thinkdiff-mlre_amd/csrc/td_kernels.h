@@ -3,7 +3,7 @@
 #pragma once
 #include "td_common.h"
 
-enum TdAct { TD_ACT_NONE = 0, TD_ACT_GELU_TANH = 1, TD_ACT_GELU_ERF = 2, TD_ACT_SILU = 3 };
+enum TdAct { TD_ACT_NONE = 0, TD_ACT_GELU_TANH = 1, TD_ACT_GELU_ERF = 2, TD_ACT_SILU = 3, TD_ACT_QUICK_GELU = 4 };
 
 struct TdGemmParams {
   const bf16_t* A = nullptr;     // [M, lda]  activations, K-contiguous
@@ -49,6 +49,8 @@ struct TdAttnParams {
   int causal = 0, causal_offset = 0;  // key visible iff key <= q + causal_offset
   int q_per_kv = 1;                   // filled by the launcher
   int variant = 0;                    // 0: shipped (lean stream), 1: first lockstep kernel (A/B only)
+  // optional additive score bias (T5 relative position bias): fp32 [Hq, Sq, Skv]; scores = q.k*scale + bias
+  const float* bias = nullptr;
 };
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);
@@ -98,3 +100,8 @@ int td_conv_pack_launch(const bf16_t* w, bf16_t* out, int Cout, int Cin, int Cou
 int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float mul, float add, hipStream_t stream);
 int td_image_finalize_launch(const bf16_t* x, int P, int Cpad, unsigned char* u8, bf16_t* chw, hipStream_t stream);
 extern "C" int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float mean, void* stream);
+
+int td_norm_rows_generic_launch(const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows, int D, int rms, float eps,
+                                const bf16_t* w, const bf16_t* b, hipStream_t stream);
+int td_add_rows_launch(const bf16_t* a, const bf16_t* b, bf16_t* out, int rows, int D, int b_rows, hipStream_t stream);
+int td_glu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, int act, hipStream_t stream);

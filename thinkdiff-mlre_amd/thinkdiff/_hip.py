@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libthinkdiff_hip.so")
 
-ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 
 _lib = None
 
@@ -63,6 +63,10 @@ def _declare(L):
         "td_flux_trace_begin": [vp, i32],
         "td_flux_trace_end": [vp, vp, vp, vp, vp],
         "td_attention_set_variant": [i32],
+        "td_layernorm_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, vp, vp, vp],
+        "td_add_rows_bf16": [vp, vp, vp, i32, i32, i32, vp],
+        "td_glu_mul_bf16": [vp, vp, i32, i32, i32, vp],
+        "td_attention_bias_bf16": [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, vp, vp],
         "td_vae_create": [vp, i32, i32, vp],
         "td_vae_num_params": [vp],
         "td_vae_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
@@ -297,3 +301,35 @@ def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-6, silu=False):
     y = torch.empty_like(x)
     check(lib().td_groupnorm_nhwc_bf16(ptr(x), ptr(y), P, C, groups, float(eps), ptr(gamma), ptr(beta), int(silu), ptr(ws), stream_ptr()))
     return y
+
+
+def layernorm(x, w=None, b=None, eps=1e-5, rms=False, out=None):
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
+    check(lib().td_layernorm_bf16(ptr(x), _rows(x), ptr(out), _rows(out), rows, D, int(rms), float(eps), ptr(w), ptr(b), stream_ptr()))
+    return out
+
+
+def add_rows(a, b):
+    rows, D = a.shape
+    out = torch.empty_like(a)
+    check(lib().td_add_rows_bf16(ptr(a), ptr(b.contiguous()), ptr(out), rows, D, b.shape[0], stream_ptr()))
+    return out
+
+
+def glu_mul(gate_up, act):
+    rows, two_i = gate_up.shape
+    out = torch.empty(rows, two_i // 2, dtype=torch.bfloat16, device=gate_up.device)
+    check(lib().td_glu_mul_bf16(ptr(gate_up), ptr(out), rows, two_i // 2, act, stream_ptr()))
+    return out
+
+
+def attention_padded(qkv, H, scale, causal=False, bias=None):
+    """qkv [S, 3*H*128] with every head zero-padded to 128 columns -> [S, H*128].  bias: fp32 [H,S,S] or None."""
+    S = qkv.shape[0]
+    W = H * 128
+    out = torch.empty(S, W, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().td_attention_bias_bf16(ptr(qkv), _rows(qkv), ptr(qkv[:, W:]), ptr(qkv[:, 2 * W:]), _rows(qkv), ptr(out), W,
+                                       S, S, H, H, float(scale), int(causal), ptr(bias), stream_ptr()))
+    return out

@@ -67,7 +67,17 @@ class FluxPipelineRewritePrompt:
         vae = None
         if os.path.isdir(os.path.join(pretrained_model_name_or_path, "vae")):
             vae = AutoencoderKLDecoder.from_pretrained(pretrained_model_name_or_path)
-        return cls(transformer=FluxTransformer2DModel.from_pretrained(pretrained_model_name_or_path, **kw), vae=vae)
+        enc = {}
+        root = pretrained_model_name_or_path
+        if os.path.isdir(os.path.join(root, "text_encoder")) and os.path.isdir(os.path.join(root, "tokenizer")):
+            from transformers import CLIPTokenizer
+            from .text_encoders import HipCLIPTextEncoder
+            enc.update(text_encoder=HipCLIPTextEncoder.from_pretrained(root), tokenizer=CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer")))
+        if os.path.isdir(os.path.join(root, "text_encoder_2")) and os.path.isdir(os.path.join(root, "tokenizer_2")):
+            from transformers import AutoTokenizer
+            from .text_encoders import HipT5Encoder
+            enc.update(text_encoder_2=HipT5Encoder.from_pretrained(root), tokenizer_2=AutoTokenizer.from_pretrained(os.path.join(root, "tokenizer_2")))
+        return cls(transformer=FluxTransformer2DModel.from_pretrained(pretrained_model_name_or_path, **kw), vae=vae, **enc)
 
     @classmethod
     def from_random(cls, config: Optional[FluxTransformerConfig] = None, seed: int = 0, with_vae: bool = True, **kw):
