@@ -189,6 +189,18 @@ int td_glu_mul_bf16(const void* gate_up, void* out, int rows, int I, int act, vo
 int td_attention_bias_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
                            int Sq, int Skv, int Hq, int Hkv, float scale, int causal, const float* bias, void* stream);
 
+/* ---- building blocks of the vision towers upstream of the aligner (EVA-ViT-g = Blip2VisionModel,
+ * thinkdiff/models/blip_vision_t5_decoder.py:611-618; Qwen2-VL ViT inside the vLLM engine,
+ * thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:1083-1089) ---- */
+/* In-place rotate_half RoPE over the first hd columns of H heads spaced head_stride apart; cos/sin fp32 [S, hd/2]. */
+int td_rope_half_bf16(void* x, int64_t ldx, int S, int H, int head_stride, int hd, const float* cos_t, const float* sin_t, void* stream);
+/* cos/sin fp32 [S, hd/2] of the 2-D vision rotary from pos int32 [S,2] = (row, column) of each patch (device). */
+int td_vision_rope_table(const int* pos, int S, int hd, float theta, float* cos_t, float* sin_t, void* stream);
+/* Conv2d(kernel = stride = p) operand: pix [C,H,W] (fp32 if src_f32 else bf16) -> out [(H/p)(W/p), Kpad] bf16, zero padded. */
+int td_patchify_bf16(const void* pix, int src_f32, int C, int H, int W, int p, void* out, int Kpad, void* stream);
+/* out[r, :K] = bf16(src[r, :K]); out[r, K:Kpad] = 0. */
+int td_cast_pad_rows_bf16(const void* src, int src_f32, int rows, int K, void* out, int Kpad, void* stream);
+
 /* ---- FLUX VAE decoder (AutoencoderKL.decode) -------------------------------------------------------------
  * Replaces the tail of the drivers' `diffusion_pipe(...)` call: [ext] diffusers 0.31.0 FluxPipeline
  * `_unpack_latents` + `latents / scaling_factor + shift_factor` + `vae.decode` + `image_processor.postprocess`
@@ -253,6 +265,8 @@ int td_qwen2_init_random(td_qwen2* f, uint64_t seed, float std, void* stream);
  * NULL); logits_last bf16[vocab] of the last token (may be NULL).  pos0 = 0 is a prefill; pos0 > 0 continues. */
 int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
                      int pos0, void* hidden_out, void* logits_last, void* stream);
+/* out bf16[n,hidden] = embed_tokens[token_ids] (device int32[n]): the host splices vision tokens into this to form inputs_embeds. */
+int td_qwen2_embed_tokens(td_qwen2* f, const int* token_ids, void* out, int n, void* stream);
 
 /* Qwen2 building blocks */
 int td_embed_gather_bf16(const int* ids, const void* table, void* out, int n, int D, int vocab, void* stream);

@@ -59,7 +59,7 @@ class ClipFluxDriver:
             self.pipe = FluxPipelineRewritePrompt.from_random(fc, seed=run.seed, max_txt_tokens=512)
         else:
             raise FileNotFoundError("no FLUX weights: set run.local_weights.flux to a local diffusers directory or run.synthetic: true")
-        self.text = providers.SyntheticTextEncoders() if self.pipe.text_encoder is None else None
+        self.text = providers.load_text_encoders(run, self.pipe, self.device)
         self.pipe.set_progress_bar_config(disable=True)
 
     # ---- config surface (reference :117-161) ---------------------------------------------------------------

@@ -90,3 +90,30 @@ def test_config_loads_unchanged_reference_yaml(name):
     cfg = Config(argparse.Namespace(cfg_path=os.path.join("/root/reference/configs", name), options=None))
     assert cfg.run_cfg.flux_num_inference_steps == 28 and cfg.run_cfg.guidance_scale == 3.5
     assert cfg.model_cfg.arch == "blip-vision-t5-decoder"
+
+
+def test_mrope_position_ids_match_transformers_get_rope_index():
+    """Qwen2VLTextEngine.expand_image_placeholders / mrope_position_ids vs transformers Qwen2VLModel.get_rope_index
+    (two images of different grids, text before / between / after)."""
+    import torch
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLModel
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextEngine as E
+    cfg = Qwen2VLConfig(text_config=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                                         intermediate_size=64, vocab_size=1024),
+                        vision_config=dict(depth=1, embed_dim=32, hidden_size=64, num_heads=2, mlp_ratio=1),
+                        image_token_id=1000, video_token_id=1001, vision_start_token_id=1002, vision_end_token_id=1003)
+    m = Qwen2VLModel(cfg)
+    grid = [[1, 8, 12], [1, 6, 6]]
+    ids = E.expand_image_placeholders([5, 6, 7, 1002, 1000, 1003, 8, 9, 1002, 1000, 1003, 10, 11, 12], grid, 2, 1000)
+    assert len(ids) == 12 + 24 + 9 and E.expand_image_placeholders(ids, grid, 2, 1000) == ids
+    pos = E.mrope_position_ids(ids, grid, 2, 1000)
+    inp = torch.tensor([ids])
+    want, _ = m.get_rope_index(inp, mm_token_type_ids=(inp == 1000).int(), image_grid_thw=torch.tensor(grid))
+    assert torch.equal(want[:, 0].int(), pos)
+    try:
+        E.expand_image_placeholders([1000], grid, 2, 1000)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("placeholder / image count mismatch must raise")

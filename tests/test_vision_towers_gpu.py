@@ -1,0 +1,165 @@
+"""GPU parity of the HIP vision towers against the modules the reference runs: transformers Blip2VisionModel
+(blip_vision_t5_decoder.py:611-618) and Qwen2VisionTransformerPretrainedModel (inside vLLM in the reference).
+Tiny random configs with the real head widths (88 and 80), bf16 on CPU.  Tolerance: relative RMSE <= 2e-2
+(same bf16 rounding points, different fp32 summation order)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def test_blip2_vision_matches_transformers(hip):
+    from transformers import Blip2VisionConfig, Blip2VisionModel
+    from thinkdiff.models.vision_towers import HipBlip2VisionModel
+    torch.manual_seed(0)
+    cfg = Blip2VisionConfig(hidden_size=704, intermediate_size=1408, num_hidden_layers=3, num_attention_heads=8, image_size=112,
+                            patch_size=14, qkv_bias=True)            # 8 heads x 88 like EVA-ViT-g; 8x8 patches + CLS = 65 tokens
+    ref = Blip2VisionModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "bias" in n:
+                p.normal_(0, 0.05)
+            elif p.dim() > 1 and "embedding" not in n:
+                p.normal_(0, 0.04)       # config initializer_range is 1e-10: re-draw so the layers matter
+            elif "norm" in n:
+                p.normal_(1.0, 0.1)
+    ref = ref.bfloat16()
+    pix = torch.randn(2, 3, 112, 112)
+    with torch.no_grad():
+        want = ref(pixel_values=pix.bfloat16())
+    tower = HipBlip2VisionModel(ref.state_dict(), num_heads=8, eps=cfg.layer_norm_eps)
+    got = tower(pix)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        skip_layers = ref.post_layernorm(ref.embeddings(pix.bfloat16()))
+    assert _rel(skip_layers, want.last_hidden_state) > 0.3       # the encoder layers are not a no-op
+    e1, e2 = _rel(got[0], want.last_hidden_state), _rel(got.pooler_output, want.pooler_output)
+    print(f"BLIP-2 ViT rel-RMSE hidden {e1:.4f} pooled {e2:.4f}")
+    assert got[0].shape == (2, 65, 704) and e1 < 2e-2 and e2 < 2e-2
+
+
+def test_qwen2_vision_matches_transformers(hip):
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLVisionConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VisionTransformerPretrainedModel
+    from thinkdiff.models.vision_towers import HipQwen2VisionTransformer
+    torch.manual_seed(1)
+    cfg = Qwen2VLVisionConfig(depth=3, embed_dim=320, hidden_size=256, num_heads=4, mlp_ratio=2, patch_size=14, temporal_patch_size=2,
+                              spatial_merge_size=2, in_channels=3)    # 4 heads x 80 like the released tower
+    ref = Qwen2VisionTransformerPretrainedModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "bias" in n:
+                p.normal_(0, 0.05)
+            elif p.dim() > 1:
+                p.mul_(2.0)
+    ref = ref.bfloat16()
+    grid = torch.tensor([[1, 8, 12], [1, 6, 6]])                     # two images: 96 + 36 patches
+    S = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+    patches = torch.randn(S, 3 * 2 * 14 * 14)
+    with torch.no_grad():
+        want = ref(patches.bfloat16(), grid_thw=grid)
+    tower = HipQwen2VisionTransformer(ref.state_dict(), num_heads=4)
+    got = tower(patches, grid)
+    torch.cuda.synchronize()
+    e1, e2 = _rel(got[0], want.last_hidden_state), _rel(got.pooler_output, want.pooler_output)
+    print(f"Qwen2-VL ViT rel-RMSE hidden {e1:.4f} merged {e2:.4f}")
+    assert got.pooler_output.shape == (S // 4, 256) and e1 < 2e-2 and e2 < 2e-2
+
+
+def test_rope_half_and_patchify_exact(hip):
+    """Bit-level checks of the two data-movement kernels against torch on the same device."""
+    from thinkdiff import _hip
+    torch.manual_seed(2)
+    S, H, hd = 37, 6, 80
+    x = torch.randn(S, H * 128 + 64, device="cuda").bfloat16()
+    ang = torch.rand(S, hd // 2, device="cuda") * 6.0
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    xv = x[:, :H * 128].reshape(S, H, 128).float()
+    a, b = xv[..., :hd // 2], xv[..., hd // 2:hd]
+    want = xv.clone()
+    want[..., :hd // 2] = a * cos[:, None] - b * sin[:, None]
+    want[..., hd // 2:hd] = b * cos[:, None] + a * sin[:, None]
+    y = x.clone()
+    _hip.rope_half(y, H, hd, cos, sin)
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, H * 128:], x[:, H * 128:])
+    got = y[:, :H * 128].reshape(S, H, 128).float()
+    assert (got - want.bfloat16().float()).abs().max() <= 2 ** -6 * want.abs().max()     # <= 1 bf16 ulp (fma contraction)
+    assert torch.equal(got[..., hd:], xv[..., hd:])
+    from thinkdiff.models.vision_towers import vision_position_ids
+    pos = vision_position_ids([[1, 8, 12], [2, 6, 6]])
+    c2, s2 = _hip.vision_rope_table(pos.to("cuda", torch.int32).contiguous(), hd)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float32) / (hd // 2)))
+    ang2 = (pos.float()[:, :, None] * inv).flatten(1)
+    assert (c2.cpu() - ang2.cos()).abs().max() < 2e-5 and (s2.cpu() - ang2.sin()).abs().max() < 2e-5
+    pix = torch.randn(3, 28, 42, device="cuda")
+    out = _hip.patchify(pix, 14, 640)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.unfold(pix[None], 14, stride=14)[0].T.bfloat16()          # [6, 588], column order c, iy, ix
+    assert torch.equal(out[:, :588], ref) and not out[:, 588:].any()
+    src = torch.randn(5, 1176, device="cuda")
+    cp = _hip.cast_pad_rows(src, 1216)
+    torch.cuda.synchronize()
+    assert torch.equal(cp[:, :1176], src.bfloat16()) and not cp[:, 1176:].any()
+
+
+def test_image_request_hidden_states_match_qwen2vl_model(hip):
+    """An image + text request end to end (processor -> ViT -> placeholder splice -> M-RoPE -> decoder) against
+    transformers Qwen2VLModel on the same pixels: the `model.norm` hidden states the reference feeds the aligner."""
+    import numpy as np
+    from PIL import Image
+    from transformers import Qwen2VLImageProcessor
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLModel
+    from thinkdiff.models.mllama_vllm_t5_embed_decoder_2 import MllamaVllmT5EmbedDecoderForConditionalGeneration_5
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig
+    from thinkdiff.models.vision_towers import HipQwen2VisionTransformer
+    IMG, VS, VE = 1000, 1002, 1003
+    cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512,
+                         vocab_size=1024, max_position_embeddings=4096, rms_norm_eps=1e-6,
+                         rope_parameters={"rope_type": "default", "mrope_section": [16, 24, 24], "rope_theta": 1e6}),
+        vision_config=dict(depth=2, embed_dim=320, hidden_size=512, num_heads=4, mlp_ratio=2),
+        image_token_id=IMG, video_token_id=1001, vision_start_token_id=VS, vision_end_token_id=VE)
+    torch.manual_seed(3)
+    ref = Qwen2VLModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() > 1 and "embed_tokens" not in n:
+                p.mul_(2.0)
+    ref = ref.bfloat16()
+    sd = ref.state_dict()
+    tsd = {"model." + k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    tsd["lm_head.weight"] = tsd["model.embed_tokens.weight"]
+    m = MllamaVllmT5EmbedDecoderForConditionalGeneration_5(
+        Qwen2VLTextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512,
+                          vocab_size=1024, tie_word_embeddings=True),
+        vllm_config={"max_model_len": 512}, hidden_size=4096,
+        visual=HipQwen2VisionTransformer({k: v for k, v in sd.items() if k.startswith("visual.")}, num_heads=4),
+        image_processor=Qwen2VLImageProcessor(min_pixels=56 * 56, max_pixels=28 * 28 * 64), image_token_id=IMG)
+    m.mllama.load_state_dict(tsd, strict=False)
+    rng = np.random.default_rng(0)
+    image = Image.fromarray((rng.random((200, 300, 3)) * 255).astype(np.uint8))
+    prompt = [5, 6, 7, VS, IMG, VE, 8, 9, 10, 11]
+    ids, emb, pos = m._splice_images(prompt, image)
+    hid, _ = m.mllama.forward(pos, None, emb)
+    torch.cuda.synchronize()
+    feats = m.image_processor(images=[image], return_tensors="pt")
+    inp = torch.tensor([ids])
+    with torch.no_grad():
+        want = ref(input_ids=inp, pixel_values=feats["pixel_values"], image_grid_thw=feats["image_grid_thw"],
+                   mm_token_type_ids=(inp == IMG).int()).last_hidden_state[0]
+    n_img = int(feats["image_grid_thw"].prod()) // 4
+    assert len(ids) == len(prompt) - 1 + n_img and hid.shape == want.shape
+    e = _rel(hid, want)
+    print(f"image request: {len(ids)} tokens ({n_img} vision) rel-RMSE {e:.4f}")
+    assert e < 2e-2
+    # and through get_embed (aligner output shape, forced continuation)
+    embeds, texts = m.get_embed([{"prompt_token_ids": prompt, "multi_modal_data": {"image": image}}], embedding_type="both",
+                                need_process=False, forced_output_ids=[[3, 4, 5]])
+    assert embeds[0].shape == (len(ids) + 3, 4096) and texts == ["3 4 5"]

@@ -197,4 +197,17 @@ int td_attention_bias_bf16(const void* q, int64_t ldq, const void* k, const void
   return td_attn_launch(p, (hipStream_t)stream);
 }
 
+int td_rope_half_bf16(void* x, int64_t ldx, int S, int H, int head_stride, int hd, const float* cos_t, const float* sin_t, void* stream) {
+  return td_rope_half_launch((bf16_t*)x, (int)ldx, S, H, head_stride, hd, cos_t, sin_t, (hipStream_t)stream);
+}
+int td_vision_rope_table(const int* pos, int S, int hd, float theta, float* cos_t, float* sin_t, void* stream) {
+  return td_vision_rope_table_launch(pos, S, hd, theta, cos_t, sin_t, (hipStream_t)stream);
+}
+int td_patchify_bf16(const void* pix, int src_f32, int C, int H, int W, int p, void* out, int Kpad, void* stream) {
+  return td_patchify_launch(pix, src_f32, C, H, W, p, (bf16_t*)out, Kpad, (hipStream_t)stream);
+}
+int td_cast_pad_rows_bf16(const void* src, int src_f32, int rows, int K, void* out, int Kpad, void* stream) {
+  return td_cast_pad_rows_launch(src, src_f32, rows, K, (bf16_t*)out, Kpad, (hipStream_t)stream);
+}
+
 }  // extern "C"

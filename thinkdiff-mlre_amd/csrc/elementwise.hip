@@ -484,3 +484,93 @@ int td_glu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, int act, h
   TD_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- vision-tower helpers -------------------------------------------------------------------------
+// In-place rotate_half RoPE on heads that sit head_stride apart (zero-padded heads): for i < hd/2
+//   x[i] <- x[i] cos_i - x[i+hd/2] sin_i,  x[i+hd/2] <- x[i+hd/2] cos_i + x[i] sin_i   (fp32, one rounding;
+// [ext] transformers qwen2_vl apply_rotary_pos_emb_vision).  cos/sin: fp32 [S, hd/2].
+__global__ void td_rope_half_kernel(bf16_t* x, int ldx, int S, int H, int head_stride, int hd, const float* cs, const float* sn) {
+  const int half = hd >> 1, per_head = half >> 1;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)S * H * per_head) return;
+  const int i = (int)(idx % per_head) * 2;
+  const int h = (int)((idx / per_head) % H);
+  const int s = (int)(idx / ((long long)per_head * H));
+  bf16_t* p = x + (size_t)s * ldx + (size_t)h * head_stride + i;
+  const unsigned a = *(const unsigned*)p, b = *(const unsigned*)(p + half);
+  const float2 c = *(const float2*)(cs + (size_t)s * half + i), n = *(const float2*)(sn + (size_t)s * half + i);
+  const float a0 = bf_lo(a), a1 = bf_hi(a), b0 = bf_lo(b), b1 = bf_hi(b);
+  *(unsigned*)p = pack_bf2(a0 * c.x - b0 * n.x, a1 * c.y - b1 * n.y);
+  *(unsigned*)(p + half) = pack_bf2(b0 * c.x + a0 * n.x, b1 * c.y + a1 * n.y);
+}
+
+int td_rope_half_launch(bf16_t* x, int ldx, int S, int H, int head_stride, int hd, const float* cs, const float* sn, hipStream_t stream) {
+  TD_CHECK_ARG(S > 0 && H > 0 && hd % 4 == 0 && hd <= head_stride && head_stride % 2 == 0 && ldx % 2 == 0, "td_rope_half: bad shape");
+  const long long n = (long long)S * H * (hd / 4);
+  hipLaunchKernelGGL(td_rope_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ldx, S, H, head_stride, hd, cs, sn);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// Conv2d(kernel = stride = p) as a GEMM operand: out[(py*gw+px), c*p*p + iy*p + ix] = pix[c, py*p+iy, px*p+ix] as bf16,
+// columns [C*p*p, Kpad) zero.  pix: [C,H,W] fp32 (src_f32) or bf16.
+__global__ void td_patchify_kernel(const void* pix, int src_f32, int C, int H, int W, int p, bf16_t* out, int Kpad) {
+  const int gw = W / p;
+  const int patch = blockIdx.x, py = patch / gw, px = patch % gw;
+  const int K = C * p * p;
+  for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (p * p), iy = (k / p) % p, ix = k % p;
+      const size_t src = ((size_t)c * H + (size_t)py * p + iy) * W + (size_t)px * p + ix;
+      v = src_f32 ? ((const float*)pix)[src] : bf2f(((const bf16_t*)pix)[src]);
+    }
+    out[(size_t)patch * Kpad + k] = f2bf(v);
+  }
+}
+
+int td_patchify_launch(const void* pix, int src_f32, int C, int H, int W, int p, bf16_t* out, int Kpad, hipStream_t stream) {
+  TD_CHECK_ARG(C > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= C * p * p, "td_patchify: image %dx%d is not a multiple of the patch %d, or Kpad too small", H, W, p);
+  hipLaunchKernelGGL(td_patchify_kernel, dim3((H / p) * (W / p)), dim3(256), 0, stream, pix, src_f32, C, H, W, p, out, Kpad);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[r, 0:K] = bf16(src[r, 0:K]), out[r, K:Kpad] = 0   (pre-flattened patches -> GEMM operand)
+__global__ void td_cast_pad_rows_kernel(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows * Kpad) return;
+  const int r = (int)(idx / Kpad), k = (int)(idx % Kpad);
+  float v = 0.f;
+  if (k < K) v = src_f32 ? ((const float*)src)[(size_t)r * K + k] : bf2f(((const bf16_t*)src)[(size_t)r * K + k]);
+  out[idx] = f2bf(v);
+}
+
+int td_cast_pad_rows_launch(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad, hipStream_t stream) {
+  TD_CHECK_ARG(rows > 0 && K > 0 && Kpad >= K, "td_cast_pad_rows: bad shape");
+  const long long n = (long long)rows * Kpad;
+  hipLaunchKernelGGL(td_cast_pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, src_f32, rows, K, out, Kpad);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// cos/sin [S, hd/2] fp32 of the Qwen2-VL vision rotary: angle[s, j] = pos[s, j >= hd/4] * theta^(-2 (j mod hd/4) / (hd/2))
+// (first half of the columns follows the patch row, second half the patch column; [ext] VisionRotaryEmbedding(head_dim/2)).
+__global__ void td_vision_rope_table_kernel(const int* pos, int S, int hd, float theta, float* cs, float* sn) {
+  const int half = hd >> 1, quarter = hd >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= S * half) return;
+  const int s = idx / half, j = idx % half;
+  const int axis = j >= quarter, f = j - axis * quarter;
+  const float inv = 1.0f / powf(theta, (float)(2 * f) / (float)half);
+  const float a = (float)pos[2 * s + axis] * inv;
+  cs[idx] = cosf(a);
+  sn[idx] = sinf(a);
+}
+
+int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, float* cs, float* sn, hipStream_t stream) {
+  TD_CHECK_ARG(pos && cs && sn && S > 0 && hd % 4 == 0, "td_vision_rope_table: bad arguments");
+  hipLaunchKernelGGL(td_vision_rope_table_kernel, dim3((S * (hd / 2) + 255) / 256), dim3(256), 0, stream, pos, S, hd, theta, cs, sn);
+  TD_CHECK_LAUNCH();
+  return 0;
+}

@@ -187,6 +187,13 @@ int td_qwen2_init_random(td_qwen2* f, uint64_t seed, float std, void* stream) {
 }
 
 // Runs n new tokens at cache positions [pos0, pos0 + n) through the decoder.
+// out[i,:] = embed_tokens[ids[i],:] -- the host builds `inputs_embeds` from this, replacing the image-placeholder
+// rows with the vision tower's merged tokens ([ext] Qwen2VLModel.forward masked_scatter).
+int td_qwen2_embed_tokens(td_qwen2* f, const int* token_ids, void* out, int n, void* stream) {
+  TD_CHECK_ARG(f && token_ids && out && n > 0, "td_qwen2_embed_tokens: null argument");
+  return td_embed_gather_launch(token_ids, f->embed_w, (bf16_t*)out, n, f->D, f->cfg.vocab, (hipStream_t)stream);
+}
+
 //   token_ids  : device int32 [n], or NULL when inputs_embeds is given
 //   inputs_embeds : device bf16 [n, hidden] (token embeddings with the image-token rows replaced by the
 //                vision tower's output), or NULL

@@ -105,3 +105,7 @@ int td_norm_rows_generic_launch(const bf16_t* x, int ldx, bf16_t* y, int ldy, in
                                 const bf16_t* w, const bf16_t* b, hipStream_t stream);
 int td_add_rows_launch(const bf16_t* a, const bf16_t* b, bf16_t* out, int rows, int D, int b_rows, hipStream_t stream);
 int td_glu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, int act, hipStream_t stream);
+int td_rope_half_launch(bf16_t* x, int ldx, int S, int H, int head_stride, int hd, const float* cs, const float* sn, hipStream_t stream);
+int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, float* cs, float* sn, hipStream_t stream);
+int td_patchify_launch(const void* pix, int src_f32, int C, int H, int W, int p, bf16_t* out, int Kpad, hipStream_t stream);
+int td_cast_pad_rows_launch(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad, hipStream_t stream);

@@ -67,6 +67,10 @@ def _declare(L):
         "td_add_rows_bf16": [vp, vp, vp, i32, i32, i32, vp],
         "td_glu_mul_bf16": [vp, vp, i32, i32, i32, vp],
         "td_attention_bias_bf16": [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, vp, vp],
+        "td_rope_half_bf16": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
+        "td_vision_rope_table": [vp, i32, i32, f32, vp, vp, vp],
+        "td_patchify_bf16": [vp, i32, i32, i32, i32, i32, vp, i32, vp],
+        "td_cast_pad_rows_bf16": [vp, i32, i32, i32, vp, i32, vp],
         "td_vae_create": [vp, i32, i32, vp],
         "td_vae_num_params": [vp],
         "td_vae_param_info": [vp, i32, ctypes.c_char_p, i32, vp],
@@ -85,6 +89,7 @@ def _declare(L):
         "td_qwen2_load_param": [vp, ctypes.c_char_p, vp, i64, vp],
         "td_qwen2_init_random": [vp, ctypes.c_uint64, f32, vp],
         "td_qwen2_forward": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
+        "td_qwen2_embed_tokens": [vp, vp, vp, i32, vp],
         "td_embed_gather_bf16": [vp, vp, vp, i32, i32, i32, vp],
         "td_silu_mul_bf16": [vp, vp, i32, i32, vp],
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],
@@ -325,11 +330,47 @@ def glu_mul(gate_up, act):
     return out
 
 
-def attention_padded(qkv, H, scale, causal=False, bias=None):
+def attention_padded(qkv, H, scale, causal=False, bias=None, out=None):
     """qkv [S, 3*H*128] with every head zero-padded to 128 columns -> [S, H*128].  bias: fp32 [H,S,S] or None."""
     S = qkv.shape[0]
     W = H * 128
-    out = torch.empty(S, W, dtype=torch.bfloat16, device=qkv.device)
+    if out is None:
+        out = torch.empty(S, W, dtype=torch.bfloat16, device=qkv.device)
+    assert out.shape == (S, W) and out.is_contiguous()
     check(lib().td_attention_bias_bf16(ptr(qkv), _rows(qkv), ptr(qkv[:, W:]), ptr(qkv[:, 2 * W:]), _rows(qkv), ptr(out), W,
                                        S, S, H, H, float(scale), int(causal), ptr(bias), stream_ptr()))
     return out
+
+
+def rope_half(x, H, hd, cos, sin, head_stride=128):
+    """In place on x [S, >= H*head_stride]; cos/sin fp32 [S, hd/2]."""
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (x.shape[0], hd // 2)
+    check(lib().td_rope_half_bf16(ptr(x), _rows(x), x.shape[0], H, head_stride, hd, ptr(cos), ptr(sin), stream_ptr()))
+    return x
+
+
+def patchify(pix, p, Kpad):
+    """pix [C,H,W] fp32|bf16 -> [(H/p)(W/p), Kpad] bf16."""
+    C, H, W = pix.shape
+    assert pix.is_contiguous() and pix.dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty((H // p) * (W // p), Kpad, dtype=torch.bfloat16, device=pix.device)
+    check(lib().td_patchify_bf16(ptr(pix), int(pix.dtype == torch.float32), C, H, W, p, ptr(out), Kpad, stream_ptr()))
+    return out
+
+
+def cast_pad_rows(src, Kpad):
+    rows, K = src.shape
+    assert src.is_contiguous() and src.dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty(rows, Kpad, dtype=torch.bfloat16, device=src.device)
+    check(lib().td_cast_pad_rows_bf16(ptr(src), int(src.dtype == torch.float32), rows, K, ptr(out), Kpad, stream_ptr()))
+    return out
+
+
+def vision_rope_table(pos, hd, theta=10000.0):
+    """pos int32 [S,2] on the device -> (cos, sin) fp32 [S, hd/2]."""
+    S = pos.shape[0]
+    assert pos.dtype == torch.int32 and pos.is_contiguous() and pos.shape[1] == 2
+    cos = torch.empty(S, hd // 2, dtype=torch.float32, device=pos.device)
+    sin = torch.empty_like(cos)
+    check(lib().td_vision_rope_table(ptr(pos), S, hd, float(theta), ptr(cos), ptr(sin), stream_ptr()))
+    return cos, sin

@@ -86,9 +86,14 @@ class BlipVisionT5DecoderForConditionalGeneration(BaseModel):
         model = cls(mm_projector_type=cfg.get("mm_projector_type", "mlp2x_gelu_t5_norm"),
                     vision_downsample_factor=cfg.get("vision_downsample_factor", None),
                     device=cfg.get("device", "cuda"))
+        import os
+        blip_dir = cfg.get("blip2_pretrained_model_name_or_path", "")
+        if blip_dir and os.path.isdir(blip_dir):
+            # reference :517-527 loads Blip2VisionModel weights from this checkpoint; here a local directory only
+            from .vision_towers import HipBlip2VisionModel
+            model.vision_model = HipBlip2VisionModel.from_pretrained(blip_dir, device=cfg.get("device", "cuda"))
         ckpt_path = cfg.get("ckpt", "")
         if ckpt_path:
-            import os
             if os.path.isfile(ckpt_path):
                 print(f"Load Checkpoint: {ckpt_path}")
                 ckpt = torch.load(ckpt_path, map_location="cpu")

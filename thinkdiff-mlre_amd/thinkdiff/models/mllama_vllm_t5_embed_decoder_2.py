@@ -6,9 +6,11 @@ Generation_5` (:779-1191): `from_config` (:838-903) and `get_embed` (:1019-1118)
 (`td_aligner_mlp2x_bf16`, fp32-norm variant: in the reference the aligner's parameters stay fp32 and run under
 bf16 autocast, :884 and scripts/test/test_mllama_t5_decoder_flux.py:149).
 
-Not built here: the Qwen2-VL vision tower and the HF chat template / tokenizer assets.  Requests
-therefore carry token ids (`{"prompt_token_ids": [...]}`, vLLM's TokensPrompt form) and, for images, precomputed
-`image_embeds` + `position_ids`; a tokenizer/processor loaded from a LOCAL path enables the text prompt form.
+Images: `visual` (vision_towers.HipQwen2VisionTransformer) + `image_processor` (the HF Qwen2-VL image processor, or any
+callable images -> {"pixel_values", "image_grid_thw"}) turn `multi_modal_data["image"]` into merged vision tokens that
+replace the `<|image_pad|>` rows of the prompt embedding, with M-RoPE positions from `mrope_position_ids`.
+The HF chat template / tokenizer assets cannot be fetched here: requests carry token ids (`{"prompt_token_ids": [...]}`,
+vLLM's TokensPrompt form) unless a tokenizer/processor loaded from a LOCAL path enables the text prompt form.
 """
 from types import SimpleNamespace
 from typing import List
@@ -30,7 +32,8 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
     PRETRAINED_MODEL_CONFIG_DICT = {"pretrain_mllama_vllm_t5_embed_decoder": "configs/models/mllama_vllm_t5_embed_decoder.yaml"}
 
     def __init__(self, text_config: Qwen2VLTextConfig = None, vllm_config: dict = None, hidden_size: int = 4096,
-                 mm_projector_type: str = "mlp2x_gelu_t5_norm", device="cuda", tokenizer=None, processor=None):
+                 mm_projector_type: str = "mlp2x_gelu_t5_norm", device="cuda", tokenizer=None, processor=None,
+                 visual=None, image_processor=None, image_token_id: int = 151655):
         vc = dict(vllm_config or {})
         self.config = SimpleNamespace(vllm_config=vc, mm_projector_type=mm_projector_type,
                                       mm_hidden_size=(text_config or Qwen2VLTextConfig()).hidden_size, hidden_size=hidden_size)
@@ -41,6 +44,8 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
             min_tokens=vc.get("min_tokens", 128), ignore_eos=vc.get("ignore_eos", True))
         self.mm_projector = HipVisionProjector(self.config.mm_hidden_size, hidden_size, mm_projector_type, device=device, fp32_norm=True)
         self.mllama_tokenizer, self.mllama_processor = tokenizer, processor
+        self.visual, self.image_token_id = visual, image_token_id
+        self.image_processor = image_processor or getattr(processor, "image_processor", None)
 
     @classmethod
     def from_config(cls, cfg):
@@ -72,6 +77,22 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
             return [{"prompt": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, images)]
         return mllama_inputs if isinstance(mllama_inputs, list) else [mllama_inputs]
 
+    def _splice_images(self, ids, images):
+        """Prompt ids with one placeholder per image -> (expanded ids, inputs_embeds [n, hidden], position_ids [3, n])."""
+        if self.visual is None or self.image_processor is None:
+            raise _hip.ThinkDiffHipError("image request: load the vision tower (visual=HipQwen2VisionTransformer...) and an "
+                                         "image_processor, or supply 'inputs_embeds' and 'position_ids' with the request")
+        images = list(images) if isinstance(images, (list, tuple)) else [images]
+        feats = self.image_processor(images=images, return_tensors="pt")
+        grid = feats["image_grid_thw"].tolist()
+        merged = self.visual(feats["pixel_values"], grid).pooler_output
+        merge = self.visual.merge
+        ids = Qwen2VLTextEngine.expand_image_placeholders(ids, grid, merge, self.image_token_id)
+        emb = self.mllama.embed_tokens(ids)
+        mask = torch.tensor(ids) == self.image_token_id
+        emb[mask.to(emb.device)] = merged
+        return ids, emb, Qwen2VLTextEngine.mrope_position_ids(ids, grid, merge, self.image_token_id)
+
     @torch.no_grad()
     def get_embed(self, mllama_inputs, embedding_type="both", output_len_factor=1, need_process=True,
                   forced_output_ids=None, generator=None, **generate_kwargs):
@@ -88,8 +109,8 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
                 raise _hip.ThinkDiffHipError("request has no 'prompt_token_ids' and no tokenizer is loaded")
             mm = r.get("multi_modal_data") or {}
             if mm.get("image") is not None and "inputs_embeds" not in r:
-                raise _hip.ThinkDiffHipError("image inputs need the Qwen2-VL vision tower (not built): supply 'inputs_embeds' "
-                                             "and 'position_ids' for the request")
+                r = dict(r)
+                ids, r["inputs_embeds"], r["position_ids"] = self._splice_images(ids, mm["image"])
             forced = None if forced_output_ids is None else forced_output_ids[i]
             outs.append(self.mllama.generate(ids, self.mllama_sampling_params, position_ids=r.get("position_ids"),
                                              inputs_embeds=r.get("inputs_embeds"), generator=generator, forced_output_ids=forced))

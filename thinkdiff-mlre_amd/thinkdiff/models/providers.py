@@ -1,10 +1,13 @@
-"""Where the not-yet-built upstream stages of the ThinkDiff-CLIP driver come from:
-the EVA-ViT-g vision tower + Blip2Processor and the CLIP-L / T5-XXL text encoders.
+"""Where the upstream stages of the ThinkDiff-CLIP driver come from: the EVA-ViT-g vision
+tower + Blip2Processor and the CLIP-L / T5-XXL text encoders.  All of them run on libthinkdiff_hip.so
+(`vision_towers.HipBlip2VisionModel`, `text_encoders.HipT5Encoder / HipCLIPTextEncoder`).
 
-* `run.local_weights.<name>` pointing at a local directory -> the Hugging Face module is loaded from disk and run
-  on the GPU through PyTorch-ROCm (interim: these stages are < 1 % of an image's FLOPs and are "next" rows);
-* `run.synthetic: true` -> seeded synthetic stand-ins with the right shapes, so the whole driver (config surface,
-  naming rules, aligner, FLUX, VAE, PNG writing) can be exercised without any asset.  Hub ids are never fetched.
+* `run.local_weights.<name>` pointing at a local directory -> weights (and the HF processor / tokenizers) are read
+  from disk;
+* `run.synthetic: true` -> full-size synthetic weights drawn on the device plus asset-free processor / tokenizer
+  stand-ins, so the whole driver (config surface, naming rules, tower, aligner, encoders, FLUX, VAE, PNG writing)
+  runs the real amount of compute without any asset; `run.synthetic_tiny: true` swaps in the cheap seeded stand-ins
+  below for plumbing tests.  Hub ids are never fetched.
 """
 import hashlib
 
@@ -53,10 +56,26 @@ class SyntheticTextEncoders:
 def load_vision(run_cfg, device):
     lw = run_cfg.get("local_weights", None) or {}
     if lw.get("blip2", None):
-        from transformers import Blip2Processor, Blip2VisionModel
-        proc = Blip2Processor.from_pretrained(lw["blip2"], local_files_only=True)
-        tower = Blip2VisionModel.from_pretrained(lw["blip2"], local_files_only=True, torch_dtype=torch.bfloat16).to(device).eval()
-        return proc, (lambda pv: tower(pixel_values=pv.to(device, torch.bfloat16))[0])
+        from transformers import Blip2Processor
+        from .vision_towers import HipBlip2VisionModel
+        return Blip2Processor.from_pretrained(lw["blip2"], local_files_only=True), HipBlip2VisionModel.from_pretrained(lw["blip2"], device=device)
     if run_cfg.get("synthetic", False):
-        return SyntheticImageProcessor(), SyntheticVisionTower()
+        if run_cfg.get("synthetic_tiny", False):
+            return SyntheticImageProcessor(), SyntheticVisionTower()
+        from .vision_towers import HipBlip2VisionModel
+        return SyntheticImageProcessor(), HipBlip2VisionModel.from_random(seed=run_cfg.get("seed", 0), device=device)
     raise FileNotFoundError("no vision tower: set run.local_weights.blip2 to a local checkpoint directory or run.synthetic: true")
+
+
+def load_text_encoders(run_cfg, pipe, device):
+    """Attach CLIP-L / T5-XXL encoders (+ tokenizers) to `pipe` when it has none.  Returns the cheap stand-in object
+    for `synthetic_tiny` runs, else None (encode_prompt then runs the HIP encoders)."""
+    if pipe.text_encoder is not None and pipe.text_encoder_2 is not None:
+        return None
+    if run_cfg.get("synthetic", False) and not run_cfg.get("synthetic_tiny", False):
+        from .text_encoders import HashTokenizer, HipCLIPTextEncoder, HipT5Encoder
+        seed = run_cfg.get("seed", 0)
+        pipe.text_encoder, pipe.tokenizer = HipCLIPTextEncoder.from_random(seed=seed + 11, device=device), HashTokenizer(49408)
+        pipe.text_encoder_2, pipe.tokenizer_2 = HipT5Encoder.from_random(seed=seed + 12, device=device), HashTokenizer(32128)
+        return None
+    return SyntheticTextEncoders()

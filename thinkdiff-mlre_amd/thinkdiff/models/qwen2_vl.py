@@ -4,7 +4,8 @@ Stands in for the `vllm.LLM(model="Qwen/Qwen2-VL-*", return_hidden_states=True)`
 (thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:790-816; thinkdiff/models/mllama_vllm_generate_1.py:382-413)
 for the part of its behaviour the ThinkDiff path uses: `generate()` returning, per request, the prompt tokens'
 and the generated tokens' hidden states at `embedding_layer_name="model.norm"` plus the generated token ids.
-The vision tower is not built: image inputs must arrive as precomputed `image_embeds`.
+Image inputs: `vision_towers.HipQwen2VisionTransformer` produces the merged vision tokens; `expand_image_placeholders`,
+`embed_tokens` and `mrope_position_ids` below do what vLLM's input processor and `get_rope_index` do around the decoder.
 """
 import ctypes
 import dataclasses
@@ -102,6 +103,57 @@ class Qwen2VLTextEngine:
         _hip.check(self._L.td_qwen2_forward(self._h, _hip.ptr(tok), _hip.ptr(emb), _hip.ptr(pos), n, pos0,
                                             _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
         return hid, lg
+
+    # ---- multimodal prompt assembly ([ext] vLLM Qwen2-VL input processor + transformers Qwen2VLModel.get_rope_index) ----
+    def embed_tokens(self, token_ids) -> torch.Tensor:
+        """[n] ids -> bf16 [n, hidden] rows of model.embed_tokens."""
+        tok = torch.as_tensor(token_ids, dtype=torch.int32).to(self.device).contiguous()
+        out = torch.empty(tok.numel(), self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _hip.check(self._L.td_qwen2_embed_tokens(self._h, _hip.ptr(tok), _hip.ptr(out), tok.numel(), _hip.stream_ptr()))
+        return out
+
+    @staticmethod
+    def expand_image_placeholders(token_ids: Sequence[int], grid_thw, merge: int = 2, image_token_id: int = 151655) -> List[int]:
+        """Each `<|image_pad|>` in the templated prompt stands for one image: repeat it t*h*w/merge^2 times (one per
+        merged vision token).  Prompts whose placeholders are already expanded pass through unchanged."""
+        counts = [int(t) * int(h) * int(w) // (merge * merge) for t, h, w in grid_thw]
+        ids = list(token_ids)
+        if sum(1 for v in ids if v == image_token_id) == sum(counts):
+            return ids
+        if sum(1 for v in ids if v == image_token_id) != len(counts):
+            raise ValueError(f"prompt holds {sum(1 for v in ids if v == image_token_id)} image placeholders for {len(counts)} images")
+        out, k = [], 0
+        for v in ids:
+            if v == image_token_id:
+                out.extend([v] * counts[k])
+                k += 1
+            else:
+                out.append(v)
+        return out
+
+    @staticmethod
+    def mrope_position_ids(token_ids: Sequence[int], grid_thw, merge: int = 2, image_token_id: int = 151655) -> torch.Tensor:
+        """int32 [3, n] (t, h, w) streams: text runs count up on all three; an image block keeps t fixed and walks
+        its merged (h/merge, w/merge) grid; the text after it resumes at max + 1."""
+        ids = list(token_ids)
+        pos = torch.zeros(3, len(ids), dtype=torch.int32)
+        i, nxt, img = 0, 0, 0
+        while i < len(ids):
+            if ids[i] == image_token_id:
+                t, h, w = (int(v) for v in grid_thw[img])
+                gh, gw = h // merge, w // merge
+                n = t * gh * gw
+                pos[0, i:i + n] = nxt + torch.arange(t, dtype=torch.int32).repeat_interleave(gh * gw)
+                pos[1, i:i + n] = nxt + torch.arange(gh, dtype=torch.int32).repeat_interleave(gw).repeat(t)
+                pos[2, i:i + n] = nxt + torch.arange(gw, dtype=torch.int32).repeat(t * gh)
+                nxt += max(t, gh, gw)
+                i += n
+                img += 1
+            else:
+                pos[:, i] = nxt
+                nxt += 1
+                i += 1
+        return pos
 
     @staticmethod
     def text_position_ids(n: int, start: int = 0) -> torch.Tensor:

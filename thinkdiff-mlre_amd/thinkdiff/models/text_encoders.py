@@ -56,6 +56,35 @@ def _read_dir(path: str, subfolder: str):
     return cfg, sd
 
 
+def _random_sd(shapes: Dict[str, tuple], seed: int, device, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Synthetic checkpoint drawn on the device: N(0, std) matrices / embeddings, unit norm weights, small biases."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in shapes.items():
+        if name.endswith(("norm.weight", "norm1.weight", "norm2.weight", "ln_q.weight", "layernorm.weight")):
+            sd[name] = torch.ones(shape, dtype=torch.bfloat16, device=device)
+        else:
+            sd[name] = (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std).to(torch.bfloat16)
+    return sd
+
+
+class HashTokenizer:
+    """Asset-free stand-in for the CLIP / T5 tokenizers (synthetic runs only): one deterministic id per
+    whitespace-separated word, EOS (= vocab - 1, the largest id) then padding to `max_length`."""
+
+    def __init__(self, vocab_size: int, pad_id: int = 0):
+        self.vocab_size, self.pad_id = vocab_size, pad_id
+
+    def __call__(self, prompt, padding="max_length", max_length=77, truncation=True, return_tensors="pt", **_kw):
+        import zlib
+        rows = []
+        for text in ([prompt] if isinstance(prompt, str) else prompt):
+            ids = [1 + zlib.crc32(w.encode()) % (self.vocab_size - 2) for w in text.split()][: max_length - 1]
+            ids.append(self.vocab_size - 1)
+            rows.append(ids + [self.pad_id] * (max_length - len(ids)))
+        return type("Encoding", (), {"input_ids": torch.tensor(rows, dtype=torch.long)})()
+
+
 class _EncoderOutput(tuple):
     """What the pipeline reads from a transformers ModelOutput: `[0]` and `.pooler_output`."""
     last_hidden_state = property(lambda self: self[0])
@@ -127,6 +156,20 @@ class HipT5Encoder(_Base):
         return self._bias_cache[S]
 
     @classmethod
+    def from_random(cls, d_model=4096, num_layers=24, num_heads=64, d_kv=64, d_ff=10240, vocab_size=32128, seed=0, device="cuda"):
+        """Synthetic flan-t5-xxl-shaped encoder (defaults) drawn on the device."""
+        shapes = {"shared.weight": (vocab_size, d_model), "encoder.final_layer_norm.weight": (d_model,),
+                  "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": (32, num_heads)}
+        for i in range(num_layers):
+            p = f"encoder.block.{i}.layer."
+            shapes.update({p + "0.SelfAttention.q.weight": (num_heads * d_kv, d_model), p + "0.SelfAttention.k.weight": (num_heads * d_kv, d_model),
+                           p + "0.SelfAttention.v.weight": (num_heads * d_kv, d_model), p + "0.SelfAttention.o.weight": (d_model, num_heads * d_kv),
+                           p + "0.layer_norm.weight": (d_model,), p + "1.layer_norm.weight": (d_model,),
+                           p + "1.DenseReluDense.wi_0.weight": (d_ff, d_model), p + "1.DenseReluDense.wi_1.weight": (d_ff, d_model),
+                           p + "1.DenseReluDense.wo.weight": (d_model, d_ff)})
+        return cls(_random_sd(shapes, seed, torch.device(device)), num_heads, d_kv, device=device)
+
+    @classmethod
     def from_pretrained(cls, path: str, subfolder: str = "text_encoder_2", device="cuda"):
         cfg, sd = _read_dir(path, subfolder)
         if cfg.get("feed_forward_proj", "gated-gelu") != "gated-gelu":
@@ -185,6 +228,20 @@ class HipCLIPTextEncoder(_Base):
                 fc1_w=g(p + "mlp.fc1.weight"), fc1_b=g(p + "mlp.fc1.bias"), fc2_w=g(p + "mlp.fc2.weight"), fc2_b=g(p + "mlp.fc2.bias")))
             i += 1
         self.fln_w, self.fln_b = g("final_layer_norm.weight"), g("final_layer_norm.bias")
+
+    @classmethod
+    def from_random(cls, hidden=768, num_layers=12, num_heads=12, intermediate=3072, vocab_size=49408, max_positions=77, seed=0, device="cuda"):
+        """Synthetic CLIP-L-shaped text model (defaults) drawn on the device."""
+        shapes = {"embeddings.token_embedding.weight": (vocab_size, hidden), "embeddings.position_embedding.weight": (max_positions, hidden),
+                  "final_layer_norm.weight": (hidden,), "final_layer_norm.bias": (hidden,)}
+        for i in range(num_layers):
+            p = f"encoder.layers.{i}."
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                shapes.update({p + f"self_attn.{n}.weight": (hidden, hidden), p + f"self_attn.{n}.bias": (hidden,)})
+            shapes.update({p + "layer_norm1.weight": (hidden,), p + "layer_norm1.bias": (hidden,), p + "layer_norm2.weight": (hidden,),
+                           p + "layer_norm2.bias": (hidden,), p + "mlp.fc1.weight": (intermediate, hidden), p + "mlp.fc1.bias": (intermediate,),
+                           p + "mlp.fc2.weight": (hidden, intermediate), p + "mlp.fc2.bias": (hidden,)})
+        return cls(_random_sd(shapes, seed, torch.device(device)), num_heads, device=device)
 
     @classmethod
     def from_pretrained(cls, path: str, subfolder: str = "text_encoder", device="cuda"):
