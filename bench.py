@@ -91,6 +91,19 @@ def cpu_baseline(threads: int):
     }
 
 
+def _pmc_traffic(kernel):
+    import glob
+    want = kernel.replace(" ", "").rstrip(">") + ","      # "td_gemm_bf16_nt_kernel<8,4," + pipeline variant, non-conv
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        with open(fn) as fh:
+            prof = json.load(fh)
+        for name, v in prof["kernels"].items():
+            if want in name.replace(" ", "") and ",false>" in name.replace(" ", ""):
+                return {"traffic": v["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                        "traffic_source": f"{os.path.basename(fn)}: {prof['source']}; {prof['correction']}"}
+    return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +203,9 @@ def main():
                 "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
                 "avg_flops_per_launch": gm["flops"] / max(gm["launches"], 1),
             }
+            # HBM bytes per launch of the same kernel from the committed PMC passes of this command (rocprofv3 cannot run
+            # inside the timed process): profiles/r*_hbm_traffic.json, made by tools/pmc_traffic.py
+            res["roofline"].update(_pmc_traffic(kern[dom]))
             res["roofline"]["sampled"] = "every launch of the kernel in the last image of the timed region (HIP events on the launch stream)"
             res["kernel_ms_per_image"] = {k: v["ms"] for k, v in cats.items()}
             at = cats["attention"]
