@@ -176,6 +176,22 @@ int td_flux_trace_end(td_flux* f, void* stream, int64_t* counts, double* ms, dou
 /* n Euler steps in place; sigmas: n+1 host floats */
 int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void* stream);
 
+/* ---- fp8 operand path (BASELINE config 5 "fp8 MFMA FLUX path") -------------------------------
+ * Operands are OCP e4m3 bytes with one fp32 dequantisation scale per row: weights per output channel (quantised once at
+ * load), activations per token (quantised by the kernel that produces them).  The contraction runs on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) at twice the bf16 MFMA rate; everything after the
+ * accumulators (bias, activation, gate, residual, bf16 rounding points) is the bf16 epilogue. */
+/* q[r,:] = e4m3(x[r,:] / s_r), s_r = max|x[r,:]| / 448 (1 for an all-zero row) -> scale[r].  K % 8 == 0. */
+int td_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream);
+/* y = epilogue((xq . wq^T) * x_scale[m] * w_scale[n]); same epilogue arguments as td_linear_bf16.  K % 128 == 0. */
+int td_linear_fp8(const void* xq, int64_t ldx, const float* x_scale, const void* wq, const float* w_scale, const void* bias,
+                  void* y, int64_t ldy, int M, int N, int K, int act, const void* gate, const void* res, int64_t ldr,
+                  int tile_cfg, void* stream);
+/* td_norm_rows_bf16 whose output row is quantised in registers: q [rows, ldq] e4m3 + q_scale[rows] (no bf16 copy). */
+int td_norm_rows_quant_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* q_scale, int rows, int D, int rms, float eps,
+                           const void* w, int split, const void* shiftA, const void* scaleA, const void* shiftB, const void* scaleB,
+                           void* stream);
+
 /* ---- building blocks of the text encoders (T5-XXL, CLIP-L) feeding encode_prompt
  * (thinkdiff/models/flux_prompt.py:88-104 -> [ext] FluxPipeline._get_t5_prompt_embeds / _get_clip_prompt_embeds) ---- */
 /* y = norm(x) for any D % 8 == 0: rms = 0 nn.LayerNorm(w, b, eps), rms = 1 T5LayerNorm(w). */

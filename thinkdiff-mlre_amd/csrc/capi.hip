@@ -210,4 +210,31 @@ int td_cast_pad_rows_bf16(const void* src, int src_f32, int rows, int K, void* o
   return td_cast_pad_rows_launch(src, src_f32, rows, K, (bf16_t*)out, Kpad, (hipStream_t)stream);
 }
 
+int td_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream) {
+  return td_quant_rows_fp8_launch((const bf16_t*)x, (int)ldx, (uint8_t*)q, (int)ldq, scale, rows, K, (hipStream_t)stream);
+}
+int td_linear_fp8(const void* xq, int64_t ldx, const float* x_scale, const void* wq, const float* w_scale, const void* bias,
+                  void* y, int64_t ldy, int M, int N, int K, int act, const void* gate, const void* res, int64_t ldr,
+                  int tile_cfg, void* stream) {
+  TdGemmParams p;
+  p.fp8 = 1; p.A = (const bf16_t*)xq; p.lda = (int)ldx; p.a_scale = x_scale;
+  p.W = (const bf16_t*)wq; p.w_scale = w_scale; p.bias = (const bf16_t*)bias;
+  p.C = (bf16_t*)y; p.ldc = (int)ldy;
+  p.gate = (const bf16_t*)gate; p.res = (const bf16_t*)res; p.ldr = (int)ldr;
+  p.M = M; p.N = N; p.K = K; p.act = act; p.cfg = tile_cfg;
+  return td_gemm_launch(p, (hipStream_t)stream);
+}
+int td_norm_rows_quant_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* q_scale, int rows, int D, int rms, float eps,
+                           const void* w, int split, const void* shiftA, const void* scaleA, const void* shiftB, const void* scaleB,
+                           void* stream) {
+  TdNormParams p;
+  p.x = (const bf16_t*)x; p.ldx = (int)ldx; p.q = (uint8_t*)q; p.ldq = (int)ldq; p.q_scale = q_scale; p.rows = rows; p.D = D;
+  p.rms = rms; p.eps = eps; p.w = (const bf16_t*)w; p.split = split;
+  p.shiftA = (const bf16_t*)shiftA; p.scaleA = (const bf16_t*)scaleA;
+  p.shiftB = (const bf16_t*)shiftB; p.scaleB = (const bf16_t*)scaleB;
+  if (p.scaleA && !p.scaleB) { p.scaleB = p.scaleA; p.shiftB = p.shiftA; }
+  TD_CHECK_ARG(q && q_scale, "td_norm_rows_quant_fp8: null output");
+  return td_norm_rows_launch(p, (hipStream_t)stream);
+}
+
 }  // extern "C"

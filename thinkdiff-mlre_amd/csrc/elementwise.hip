@@ -22,6 +22,16 @@ __device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
 
 }  // namespace
 
+// 8 floats * inv -> 8 OCP e4m3 bytes (v_cvt_pk_fp8_f32, round to nearest even; |x * inv| <= 448 by construction)
+__device__ __forceinline__ u32x2_t pack8_fp8(const float (&x)[8], float inv) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * inv, x[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * inv, x[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * inv, x[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv, x[7] * inv, hi, true);
+  return u32x2_t{(unsigned)lo, (unsigned)hi};
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row normalisation (+ optional affine weight, + optional adaLN modulation), one wave per row.
 //   LayerNorm (no affine, eps) : n = (x - mean) * rsqrt(var + eps)          [diffusers AdaLayerNorm*]
@@ -61,6 +71,7 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
   const bf16_t* shift = partB ? p.shiftB : p.shiftA;
   const bf16_t* scale = partB ? p.scaleB : p.scaleA;
   bf16_t* yr = p.y + (size_t)row * p.ldy;
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
@@ -81,7 +92,24 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
 #pragma unroll
       for (int i = 0; i < 8; ++i) y[i] = rbf(rbf(y[i] * rbf(1.0f + sc[i])) + sh[i]);
     }
-    *(u32x4_t*)(yr + col) = pack8(y);
+    if (p.q) {   // keep the bf16-rounded row in registers for the quantisation pass
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[c][i] = rbf(y[i]);
+        amax = fmaxf(amax, fabsf(v[c][i]));
+      }
+    } else {
+      *(u32x4_t*)(yr + col) = pack8(y);
+    }
+  }
+  if (p.q) {
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) p.q_scale[row] = s;
+    uint8_t* qr = p.q + (size_t)row * p.ldq;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *(u32x2_t*)(qr + c * 512 + lane * 8) = pack8_fp8(v[c], inv);
   }
 }
 
@@ -90,6 +118,7 @@ int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.D % 512 == 0 && p.D <= 4096, "td_norm_rows: D=%d must be a multiple of 512, <= 4096", p.D);
   TD_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0, "td_norm_rows: row strides must be multiples of 8");
   TD_CHECK_ARG((p.scaleA == nullptr) == (p.shiftA == nullptr), "td_norm_rows: shift and scale come together");
+  if (p.q) TD_CHECK_ARG(p.q_scale && p.ldq % 8 == 0 && (uintptr_t)p.q % 8 == 0, "td_norm_rows: fp8 output needs a scale array and 8-byte aligned rows");
   const dim3 grid((p.rows + 3) / 4), block(256);
   switch (p.D / 512) {
 #define TD_CASE(n) case n: hipLaunchKernelGGL(td_norm_rows_kernel<n>, grid, block, 0, stream, p); break;
@@ -571,6 +600,39 @@ __global__ void td_vision_rope_table_kernel(const int* pos, int S, int hd, float
 int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, float* cs, float* sn, hipStream_t stream) {
   TD_CHECK_ARG(pos && cs && sn && S > 0 && hd % 4 == 0, "td_vision_rope_table: bad arguments");
   hipLaunchKernelGGL(td_vision_rope_table_kernel, dim3((S * (hd / 2) + 255) / 256), dim3(256), 0, stream, pos, S, hd, theta, cs, sn);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---- per-row dynamic fp8 (OCP e4m3) quantisation: weights at load time (per output channel), activations per token ----
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  float amax = 0.f;
+  for (int c = lane * 8; c < K; c += 512) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(xr + c), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  }
+  amax = wave_max(amax);
+  const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / s;
+  if (lane == 0) scale[row] = s;
+  uint8_t* qr = q + (size_t)row * ldq;
+  for (int c = lane * 8; c < K; c += 512) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(xr + c), v);
+    *(u32x2_t*)(qr + c) = pack8_fp8(v, inv);
+  }
+}
+
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream) {
+  TD_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_fp8: bad arguments");
+  hipLaunchKernelGGL(td_quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, q, ldq, scale, rows, K);
   TD_CHECK_LAUNCH();
   return 0;
 }

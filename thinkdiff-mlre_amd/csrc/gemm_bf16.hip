@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int BK = 64;          // bf16 elements per K tile (= one 128-B LDS row)
+[[maybe_unused]] constexpr int BK = 64;          // bf16 elements per K tile (= one 128-B LDS row)
 constexpr int ROW_BYTES = 128;  // LDS row pitch
 
 template <int ACT>
@@ -140,7 +140,12 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
 
 }  // namespace
 
-template <int WM, int WN, int VARIANT = 2, bool CONV = false>
+// FP8: both operands are OCP e4m3 bytes (K-contiguous, 128 elements = one 128-B LDS row per k-tile, so the staging
+// and the swizzle are byte-for-byte those of the bf16 kernel); the two 16-B fragment reads of a lane feed ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 MFMA rate).  The k <-> (lane, byte) map of the
+// instruction does not matter: both operands are read with the same map and the contraction sums over all k.
+// Dequantisation is per output row (a_scale[m]) x per output column (w_scale[n]) on the fp32 accumulators.
+template <int WM, int WN, int VARIANT = 2, bool CONV = false, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   constexpr int BM = 32 * WM, BN = 64 * WN;
@@ -148,6 +153,8 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   constexpr int GA = BM / 8, GW = BN / 8;           // 8-row staging groups per tile
   constexpr int SA = (GA + 7) / 8, SW = (GW + 7) / 8;  // staging instructions per wave
   constexpr int NV = 4 * WN;                          // contiguous output columns per lane
+  constexpr unsigned ESZ = FP8 ? 1u : 2u;             // operand element size in bytes
+  static_assert(!FP8 || (VARIANT == 2 && !CONV), "the fp8 path exists for the shipped pipeline only");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -186,8 +193,8 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
   const unsigned bytesA = CONV ? (unsigned)((long long)(p.conv_H >> p.conv_up) * (p.conv_W >> p.conv_up) * p.conv_Cin * 2)
-                                : (unsigned)(((long long)(pv.M - 1) * p.lda + p.K) * 2);
-  const unsigned bytesW = (unsigned)((long long)p.N * p.K * 2);
+                                : (unsigned)(((long long)(pv.M - 1) * p.lda + p.K) * ESZ);
+  const unsigned bytesW = (unsigned)((long long)p.N * p.K * ESZ);
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Aptr, 0, bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wptr, 0, bytesW, 0x00020000);
 
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     int g = wid + 8 * s;
     if (GA % 8 != 0 && g >= GA) g %= GA;
     const int row = m0 + g * 8 + srow;
-    voffS[s] = (unsigned)row * (unsigned)p.lda * 2u + schunk;
+    voffS[s] = (unsigned)row * (unsigned)p.lda * ESZ + schunk;
     ldsS[s] = g * 1024;
   }
 #pragma unroll
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     const int rem = rho - wcol * (16 * WN);
     const int j = rem >> 4, i16 = rem & 15;
     const int n = n0 + wcol * (16 * WN) + (i16 >> 2) * NV + j * 4 + (i16 & 3);
-    voffS[SA + s] = (unsigned)n * (unsigned)p.K * 2u + schunk;
+    voffS[SA + s] = (unsigned)n * (unsigned)p.K * ESZ + schunk;
     ldsS[SA + s] = g * 1024;
   }
   // Implicit-GEMM 3x3 convolution (CONV): A is an NHWC image [Hin*Win, Cin]; k-tile kt covers tap kt / (Cin/64)
@@ -270,9 +277,74 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 #pragma unroll
     for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / BK;
+  const int nt = p.K / (FP8 ? 2 * BK : BK);      // a k-tile is one 128-B row: 64 bf16 or 128 fp8
 #pragma unroll
   for (int s = 0; s < NS; ++s) stage_one(s, 0, 0, 0);
+  if constexpr (FP8) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+    auto frag = [&](const char* base) -> i32x8_t {   // the lane's 16-B chunks of both 64-B halves of the row
+      const i32x4_t lo = *(const i32x4_t*)(base + foff0), hi = *(const i32x4_t*)(base + (foff0 ^ 64));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int s = SA; s < NS; ++s) stage_one(s, 0, 1, min(1, nt - 1));
+    int wcur = 0;
+    constexpr int MASK_VMEM = 0x010, MASK_DS_READ = 0x100, MASK_MFMA = 0x008;
+    constexpr int S_PER_IT = (NS + WM - 1) / WM;
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* wb = smem + W_REGION + wcur * W_BYTES + woff;
+      const char* ab = smem + (t & 1) * A_BYTES + aoff;
+      const int kt_a = min(t + 1, nt - 1), kt_w = min(t + 2, nt - 1);
+      const int abuf_next = (t + 1) & 1;
+      const int wbuf_next = wcur == 0 ? 2 : wcur - 1;
+      wcur = wcur == 2 ? 0 : wcur + 1;
+      i32x8_t wf[WN], af[2];
+      wf[0] = frag(wb);
+      af[0] = frag(ab);
+      __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 4, 0);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int cur = i & 1;
+        int nst = 0;
+#pragma unroll
+        for (int q = 0; q < S_PER_IT; ++q) {
+          const int s = i * S_PER_IT + q;
+          if (s < NS) { stage_one(s, abuf_next, wbuf_next, s < SA ? kt_a : kt_w); ++nst; }
+        }
+        if (i == 0) {
+#pragma unroll
+          for (int j = 1; j < WN; ++j) wf[j] = frag(wb + j * 16 * ROW_BYTES);
+        }
+        if (i + 1 < WM) af[cur ^ 1] = frag(ab + (i + 1) * 16 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[cur], acc[j][i], 0, 0, 0, 127, 0, 127);
+        switch (nst) {
+          case 1: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 1, 0); break;
+          case 2: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 2, 0); break;
+          case 3: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 3, 0); break;
+          case 4: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 4, 0); break;
+          case 5: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 5, 0); break;
+          default: break;
+        }
+        if (i == 0) {
+          // the remaining W fragments arrive one MFMA ahead of their use; the next A fragment behind the last
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            if (j + 1 < WN) __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 2, 0);
+            else if (WM > 1) __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(MASK_MFMA, 1, 0);
+          }
+        } else {
+          if (i + 1 < WM) __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(MASK_MFMA, WN, 0);
+        }
+      }
+    }
+  } else
   if constexpr (VARIANT == 0) {
     // baseline structure kept for in-process A/B runs: stage the next tile up front, then all fragment
     // reads of a k-step followed by its MFMAs (compiler-scheduled)
@@ -396,6 +468,26 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   const bool second = (p.C2 != nullptr) && (n0 >= p.n_split);
   const int act = second ? p.act2 : p.act;
   const int mbeg = m0 + wr * 16 * WM + frow;
+  if constexpr (FP8) {   // y = (sum q_a q_w) * a_scale[row] * w_scale[col]
+    const float* sa = second_prob ? p.g_a_scale : p.a_scale;
+    const float* sw = second_prob ? p.g_w_scale : p.w_scale;
+    float swv[NV];
+#pragma unroll
+    for (int c = 0; c < NV; c += 4) {
+      f32x4_t w4 = {0.f, 0.f, 0.f, 0.f};
+      if (nbeg + c + 4 <= p.N) w4 = *(const f32x4_t*)(sw + nbeg + c);
+      swv[c] = w4[0]; swv[c + 1] = w4[1]; swv[c + 2] = w4[2]; swv[c + 3] = w4[3];
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int m = mbeg + i * 16;
+      const float sr = m < pv.M ? sa[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][i][r] *= sr * swv[j * 4 + r];
+    }
+  }
   // one instantiation per activation keeps every acc[][] index static (runtime-indexed
   // accumulators would be demoted to scratch)
   // (an activation followed by a gate / residual does not occur on this path: act wins, as before the split)
@@ -414,7 +506,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 
 namespace {
 
-template <int WM, int WN, int VARIANT = 2, bool CONV = false>
+template <int WM, int WN, int VARIANT = 2, bool CONV = false, bool FP8 = false>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int LDS = (2 * BM + (VARIANT == 2 ? 3 : 2) * BN) * ROW_BYTES;
@@ -425,12 +517,12 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   static bool attr_set = false;
   if (!attr_set) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV>,
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV, FP8>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV, FP8>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -451,12 +543,13 @@ int td_gemm_config_id(int M, int N, int K) {
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "td_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
-  TD_CHECK_ARG(p.K % BK == 0, "td_gemm: K=%d must be a multiple of %d", p.K, BK);
+  const int esz = p.fp8 ? 1 : 2;
+  TD_CHECK_ARG(p.K % (128 / esz) == 0, "td_gemm: K=%d must be a multiple of %d", p.K, 128 / esz);
   TD_CHECK_ARG(p.N % 8 == 0, "td_gemm: N=%d must be a multiple of 8", p.N);
   TD_CHECK_ARG((p.conv_H > 0 || p.lda >= p.K) && p.ldc >= (p.C2 ? p.n_split : p.N), "td_gemm: bad leading dimensions");
-  TD_CHECK_ARG(((long long)(p.M + 255) * p.lda + p.K) * 2 < (1ll << 32) && (long long)(p.N + 255) * p.K * 2 < (1ll << 32),
+  TD_CHECK_ARG(((long long)(p.M + 255) * p.lda + p.K) * esz < (1ll << 32) && (long long)(p.N + 255) * p.K * esz < (1ll << 32),
                "td_gemm: operand exceeds the 4 GiB buffer-descriptor range");
-  TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C) % 16 == 0 && p.lda % 8 == 0 && p.ldc % 8 == 0,
+  TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C) % 16 == 0 && p.lda % (16 / esz) == 0 && p.ldc % 8 == 0,
                "td_gemm: pointers / leading dimensions must be 16-byte aligned");
   if (p.res) TD_CHECK_ARG(p.ldr % 4 == 0, "td_gemm: ldr must be a multiple of 4");
   if (p.C2) TD_CHECK_ARG(p.ldc2 % 8 == 0 && p.n_split % 8 == 0 && p.n_split < p.N, "td_gemm: bad split-output arguments");
@@ -470,7 +563,16 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_ARG(p.conv_up == 0 || (p.conv_H % 2 == 0 && p.conv_W % 2 == 0), "td_gemm(conv): upsampled output dims must be even");
     return p.N <= 64 ? launch_cfg<8, 1, 2, true>(p, stream) : launch_cfg<8, 4, 2, true>(p, stream);
   }
-  const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K);
+  const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
+  if (p.fp8) {
+    TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,
+                 "td_gemm(fp8): row / column dequantisation scales are required; no conv / fp32-out form");
+    switch (cfg) {
+      case 2: return launch_cfg<1, 4, 2, false, true>(p, stream);
+      case 3: return launch_cfg<9, 3, 2, false, true>(p, stream);
+      default: return launch_cfg<8, 4, 2, false, true>(p, stream);
+    }
+  }
   switch (cfg) {   // 0-3: shipped pipeline (VARIANT 2); 1x / 3x: earlier loop structures kept for in-process A/B
     case 1: return launch_cfg<8, 1, 2>(p, stream);
     case 2: return launch_cfg<1, 4, 2>(p, stream);

@@ -27,6 +27,10 @@ struct TdGemmParams {
   // implicit-GEMM 3x3 convolution over an NHWC image (conv_H > 0): A = input [Hin*Win, Cin], W = [N, 9*Cin]
   // (k = tap*Cin + c, tap = ky*3+kx), M = conv_H*conv_W output pixels; conv_up = 1 fuses a nearest 2x upsample
   int conv_H = 0, conv_W = 0, conv_Cin = 0, conv_up = 0;
+  // fp8 operands (fp8 = 1): A and W hold OCP e4m3 bytes (lda, K in elements = bytes); y = acc * a_scale[m] * w_scale[n]
+  int fp8 = 0;
+  const float* a_scale = nullptr; const float* w_scale = nullptr;        // [M], [N]
+  const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
 };
 
@@ -65,7 +69,11 @@ struct TdNormParams {
   int split = 0;              // rows < split use set A, others set B
   const bf16_t* shiftA = nullptr; const bf16_t* scaleA = nullptr;
   const bf16_t* shiftB = nullptr; const bf16_t* scaleB = nullptr;
+  // fp8 output (q != null): the row is written as OCP e4m3 q[row, :] = fp8(y / s), s = max|y| / 448 -> q_scale[row]; y unused
+  uint8_t* q = nullptr; int ldq = 0; float* q_scale = nullptr;
 };
+// per-row dynamic fp8 quantisation of a bf16 matrix: q[r,:] = e4m3(x[r,:] / s_r), s_r = max|x[r,:]| / 448 (1 for a zero row)
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream);
 int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream);
 
 struct TdQkRopeParams {

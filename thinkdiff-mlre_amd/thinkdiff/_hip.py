@@ -63,6 +63,9 @@ def _declare(L):
         "td_flux_trace_begin": [vp, i32],
         "td_flux_trace_end": [vp, vp, vp, vp, vp],
         "td_attention_set_variant": [i32],
+        "td_quant_rows_fp8": [vp, i64, vp, i64, vp, i32, i32, vp],
+        "td_linear_fp8": [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, i32, vp],
+        "td_norm_rows_quant_fp8": [vp, i64, vp, i64, vp, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp],
         "td_layernorm_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, vp, vp, vp],
         "td_add_rows_bf16": [vp, vp, vp, i32, i32, i32, vp],
         "td_glu_mul_bf16": [vp, vp, i32, i32, i32, vp],
@@ -374,3 +377,33 @@ def vision_rope_table(pos, hd, theta=10000.0):
     sin = torch.empty_like(cos)
     check(lib().td_vision_rope_table(ptr(pos), S, hd, float(theta), ptr(cos), ptr(sin), stream_ptr()))
     return cos, sin
+
+
+# ---- fp8 operand path --------------------------------------------------------------------------------------------
+def quant_rows_fp8(x):
+    """bf16 [R,K] -> (uint8 e4m3 [R,K], fp32 scale [R])."""
+    R, K = x.shape
+    q = torch.empty(R, K, dtype=torch.uint8, device=x.device)
+    s = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(lib().td_quant_rows_fp8(ptr(x), _rows(x), ptr(q), K, ptr(s), R, K, stream_ptr()))
+    return q, s
+
+
+def linear_fp8(xq, xs, wq, ws, bias=None, act=ACT_NONE, gate=None, res=None, out=None, tile_cfg=-1):
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and wq.shape[1] == K and wq.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=xq.device)
+    check(lib().td_linear_fp8(ptr(xq), xq.stride(0), ptr(xs), ptr(wq), ptr(ws), ptr(bias), ptr(out), _rows(out), M, N, K, act,
+                              ptr(gate), ptr(res), _rows(res) if res is not None else 0, tile_cfg, stream_ptr()))
+    return out
+
+
+def norm_rows_quant_fp8(x, rms=False, eps=1e-6, w=None, split=0, shiftA=None, scaleA=None, shiftB=None, scaleB=None):
+    R, D = x.shape
+    q = torch.empty(R, D, dtype=torch.uint8, device=x.device)
+    s = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(lib().td_norm_rows_quant_fp8(ptr(x), _rows(x), ptr(q), D, ptr(s), R, D, int(rms), float(eps), ptr(w), split,
+                                       ptr(shiftA), ptr(scaleA), ptr(shiftB), ptr(scaleB), stream_ptr()))
+    return q, s

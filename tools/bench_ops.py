@@ -62,6 +62,33 @@ def bench_gemmcfg():
         print(f"M={M0}+{M1} N={N} K={K}:  " + "   ".join(f"cfg{c}: {best[c]:7.3f} ms {fl/best[c]/1e9:7.1f} TF/s" for c in cfgs), flush=True)
 
 
+def bench_gemmfp8():
+    """fp8 (e4m3, v_mfma_scale 16x16x128) vs bf16 GEMM on the LN-fed FLUX shapes, cold weights (pool cycling), interleaved."""
+    for M, N, K in [(4289, 21504, 3072), (4289, 9216, 3072), (4289, 12288, 3072), (4289, 3072, 12288), (4289, 3072, 15360)]:
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        npool = max(2, int(1.2e9 // (N * K * 2)))
+        pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(npool)]
+        qpool = [_hip.quant_rows_fp8(w) for w in pool]
+        xq, xs = _hip.quant_rows_fp8(x)
+        b = torch.randn(N, device="cuda").bfloat16()
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        fl = 2.0 * M * N * K
+        st = {"i": 0}
+        def f_bf16():
+            st["i"] = (st["i"] + 1) % npool
+            _hip.linear(x, pool[st["i"]], b, out=y)
+        def f_fp8():
+            st["i"] = (st["i"] + 1) % npool
+            wq, ws = qpool[st["i"]]
+            _hip.linear_fp8(xq, xs, wq, ws, b, out=y)
+        best = {"bf16": 1e9, "fp8": 1e9}
+        for rnd in range(4):
+            best["bf16"] = min(best["bf16"], timeit(f_bf16, iters=10, warmup=2))
+            best["fp8"] = min(best["fp8"], timeit(f_fp8, iters=10, warmup=2))
+        print(f"M={M} N={N} K={K}: bf16 {best['bf16']:7.3f} ms {fl/best['bf16']/1e9:7.1f} TF/s   fp8 {best['fp8']:7.3f} ms {fl/best['fp8']/1e9:7.1f} TF/s   x{best['bf16']/best['fp8']:.2f}", flush=True)
+        del pool, qpool
+
+
 def bench_gemmcold():
     """Tile/pipeline variants with L3-warm weights (one W re-used) vs cold weights (cycling a 1 GB pool, as in
     the real denoise loop where every layer's weights stream from HBM).  Interleaved rounds, best-of."""
