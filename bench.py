@@ -29,6 +29,7 @@ NUM_STEPS = 28
 T_TXT = 193            # 65 aligner tokens + 128 T5 tokens
 GUIDANCE = 3.5
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+FP8_DENSE_PEAK_TFLOPS = 5000.0
 
 
 def flux_flops_per_forward(s_img: int, s_txt: int) -> float:
@@ -111,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip the per-launch HIP-event trace (roofline leg)")
+    ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
+                    help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +132,7 @@ def main():
     from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
     pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=256, max_steps=32)
     tr = pipe.transformer
+    tr.set_precision(a.precision)
 
     # synthetic inputs (SURVEY.md 8d cfg 2), seed + rank as the reference drivers do
     g = torch.Generator().manual_seed(42 + rank)
@@ -179,14 +183,15 @@ def main():
             "metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if a.precision == "bf16" else "fp8_e4m3 block-GEMM operands (per-channel weight / per-token activation scales), fp32 accumulate, bf16 elsewhere",
+            "data": "synthetic",
             "config": {
                 "workload": ("BASELINE config 2: ThinkDiff-CLIP single image+text, FLUX.1-dev shape (11.9 B params, seeded "
                              "random init), 1024x1024, 28 Euler steps, T_txt=193 (65 aligner + 128 T5), joint S=4289, "
                              "guidance 3.5; step = one image per rank, from HBM-resident prompt_embeds/pooled/latents through the 28-step "
                              "denoise loop, VAE decode (FLUX.1-dev VAE shape, seeded random init) and uint8 conversion to a host "
                              "PIL image -- the reference driver's diffusion_pipe(...).images[0]"),
-                "images_per_rank_per_step": 1, "parallelism": f"dp{world} (independent images, seed+rank)",
+                "precision": a.precision, "images_per_rank_per_step": 1, "parallelism": f"dp{world} (independent images, seed+rank)",
                 "algorithmic_pflop_per_image": flops_img / 1e15,
             },
             "whole_step_tflops_per_gpu": flops_img / (elapsed / a.steps) / 1e12,
@@ -196,16 +201,18 @@ def main():
             dom = max(kern, key=lambda k: cats[k]["ms"])      # the GEMM tile variant with the most device time
             gm = cats[dom]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            peak = BF16_DENSE_PEAK_TFLOPS if a.precision == "bf16" else FP8_DENSE_PEAK_TFLOPS
             res["roofline"] = {
-                "bound": "mfma", "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-                "kernel": kern[dom],
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None,
+                "kernel": kern[dom] if a.precision == "bf16" else kern[dom].replace(">", ",fp8>"),
                 "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
                 "avg_flops_per_launch": gm["flops"] / max(gm["launches"], 1),
             }
             # HBM bytes per launch of the same kernel from the committed PMC passes of this command (rocprofv3 cannot run
             # inside the timed process): profiles/r*_hbm_traffic.json, made by tools/pmc_traffic.py
-            res["roofline"].update(_pmc_traffic(kern[dom]))
+            if a.precision == "bf16":
+                res["roofline"].update(_pmc_traffic(kern[dom]))
             res["roofline"]["sampled"] = "every launch of the kernel in the last image of the timed region (HIP events on the launch stream)"
             res["kernel_ms_per_image"] = {k: v["ms"] for k, v in cats.items()}
             at = cats["attention"]

@@ -157,6 +157,12 @@ int td_flux_num_params(const td_flux* f);
 int td_flux_param_info(const td_flux* f, int idx, char* name_buf, int buf_len, int64_t* count);
 /* copy one parameter (device bf16, `count` elements) into the engine's fused weight arena */
 int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t count, void* stream);
+/* Operand precision of the block GEMMs.  TD_PRECISION_FP8_E4M3 quantises every double-/single-stream Linear weight per
+ * output channel from the parameters as loaded NOW (call after loading; call again after reloading) and runs those GEMMs on
+ * the fp8 MFMA path with per-token dynamic activation scales (BASELINE config 5).  Accumulation, epilogues, attention,
+ * normalisation and the residual stream stay as in the bf16 path. */
+enum { TD_PRECISION_BF16 = 0, TD_PRECISION_FP8_E4M3 = 1 };
+int td_flux_set_precision(td_flux* f, int precision, void* stream);
 int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream);
 /* per prompt: prompt_embeds bf16 [T,joint_dim], pooled bf16 [pooled_dim], ids fp32 device [n,3]
  * (txt_ids NULL = zeros, thinkdiff/models/flux_prompt.py:119) */

@@ -149,8 +149,29 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tenso
     return y * w
 
 
+# fp8 operand mode (BASELINE config 5; restates csrc/flux_engine.hip td_flux_set_precision): every Linear inside the
+# double-/single-stream blocks except the adaLN modulation linears takes OCP e4m3 operands -- weights quantised per output
+# channel, activations per token, both with scale = max|.| / 448 -- accumulates exactly, dequantises, adds the bias and
+# rounds once to the working dtype.  Off by default: the reference itself has no fp8 path.
+FP8_BLOCK_LINEARS = False
+
+
+def _quant_rows_e4m3(x2d):
+    xf = x2d.float()
+    amax = xf.abs().amax(dim=1)
+    s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    return (xf * (1.0 / s)[:, None]).to(torch.float8_e4m3fn).float(), s
+
+
 def _lin(sd, name, x):
-    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+    w, b = sd[name + ".weight"], sd[name + ".bias"]
+    in_block = name.startswith(("transformer_blocks.", "single_transformer_blocks."))
+    if FP8_BLOCK_LINEARS and in_block and ".norm" not in name:
+        xq, sx = _quant_rows_e4m3(x.reshape(-1, x.shape[-1]))
+        wq, sw = _quant_rows_e4m3(w)
+        y = (xq.double() @ wq.double().T).float() * sx[:, None] * sw[None, :] + b.float()
+        return y.to(x.dtype).reshape(*x.shape[:-1], w.shape[0])
+    return F.linear(x, w, b)
 
 
 def _ln(x):

@@ -82,3 +82,35 @@ def test_denoise_loop_matches_oracle(hip):
     e = _rel_rmse(x[None], ref)
     print(f"denoise rel-RMSE vs bf16 oracle: {e:.4f}")
     assert e < 2e-2
+
+
+@pytest.mark.parametrize("layers,singles,h2,w2,T", [(2, 3, 16, 16, 193), (1, 1, 12, 20, 65)])
+def test_fp8_mode_matches_fp8_oracle(hip, layers, singles, h2, w2, T):
+    """BASELINE config 5 (fp8 operands): the engine in fp8 mode against the oracle with the same operand quantisation
+    (oracle.flux_ref.FP8_BLOCK_LINEARS), and the size of the fp8 deviation from the bf16 pipeline.
+    Tolerances: <= 3e-2 relative RMSE against the fp8 oracle (bf16 bar 2e-2 plus e4m3 near-tie flips between two
+    pipelines with different fp32 summation orders); fp8-vs-bf16 deviation reported and bounded by 0.15."""
+    cfg = R.tiny_config(num_layers=layers, num_single_layers=singles)
+    sd, m = _build(cfg, seed=layers * 10 + singles)
+    lat, pe, pool = _inputs(cfg, h2, w2, T, seed=T)
+    img_ids = R.latent_image_ids(h2, w2)
+    txt_ids = torch.zeros(T, 3)
+    t, g = torch.tensor([0.7324]), torch.tensor([3.5])
+    args = (sd, cfg, lat, pe, pool, t.bfloat16(), img_ids.bfloat16(), txt_ids.bfloat16(), g)
+    ref16 = R.transformer_forward(*args)
+    R.FP8_BLOCK_LINEARS = True
+    try:
+        ref8 = R.transformer_forward(*args)
+    finally:
+        R.FP8_BLOCK_LINEARS = False
+    out16 = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0].clone()
+    m.set_precision("fp8")
+    out8 = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0].clone()
+    m.set_precision("bf16")
+    back = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0]
+    torch.cuda.synchronize()
+    e88, e816, o816 = _rel_rmse(out8, ref8), _rel_rmse(out8, out16), _rel_rmse(ref8, ref16)
+    print(f"rel-RMSE hip-fp8~oracle-fp8 {e88:.4f}   hip-fp8~hip-bf16 {e816:.4f}   oracle-fp8~oracle-bf16 {o816:.4f}")
+    assert e88 < 3e-2
+    assert e816 < 0.15 and abs(e816 - o816) < 0.5 * o816 + 1e-2
+    assert torch.equal(back, out16)            # switching back restores the bf16 path bit for bit

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const 
 // K row reads, 8 for the V transposed reads; k-block / k-step / tile-slot parts are instruction immediates
 // and one XOR per register per tile flips the double-buffer slot).
 // ---------------------------------------------------------------------------------------------
-template <bool CAUSAL, int NWAVES>
+template <bool CAUSAL, int NWAVES, bool BIAS = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(const TdAttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1]
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     }
 
     const int key0 = t * KV_TILE;
-    if (p.bias) {   // additive score bias in the scaled domain: (s + bias/scale) * scale = s*scale + bias
+    if constexpr (BIAS) {   // additive score bias in the scaled domain: (s + bias/scale) * scale = s*scale + bias
       const float inv_scale = 1.0f / p.scale;
       const int qrow = min(q0 + l31, p.Sq - 1);
       const float* bp = p.bias + ((size_t)head * p.Sq + qrow) * p.Skv + key0 + 4 * h5;
@@ -549,6 +549,8 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
     TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<true, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
     TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
     TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<false, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<true, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
     attr_set = true;
   }
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
@@ -557,6 +559,9 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   if (p.variant == 1 && !p.bias) {
     if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW, false>), grid, dim3(NW * 64), lds, stream, q);
     else hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW, false>), grid, dim3(NW * 64), lds, stream, q);
+  } else if (p.bias) {   // separate instantiation: the score-bias loads must not touch the hot no-bias instruction stream
+    if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW, true>), grid, dim3(NW * 64), lds, stream, q);
+    else hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
   } else {
     if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW>), grid, dim3(NW * 64), lds, stream, q);
     else hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW>), grid, dim3(NW * 64), lds, stream, q);

@@ -48,6 +48,13 @@ struct SingleW {
   bf16_t *w2, *b2;  // proj_out [D, D + M]
   bf16_t *norm_q, *norm_k;
 };
+// fp8 mode (td_flux_set_precision): e4m3 copy of a block weight [rows, K] + one dequantisation scale per output channel
+struct Fp8Mat {
+  uint8_t* q = nullptr;
+  float* s = nullptr;
+};
+struct DoubleW8 { Fp8Mat qkv_img, qkv_ctx, out_img, out_ctx, ff1_img, ff1_ctx, ff2_img, ff2_ctx; };
+struct SingleW8 { Fp8Mat w1, w2; };
 
 }  // namespace
 
@@ -69,6 +76,13 @@ struct td_flux {
   bf16_t *h, *xn, *qkv, *attn, *mlp, *cat, *ctx, *vout;
   bf16_t *tproj, *tmid, *te, *gproj, *gmid, *ge, *pmid, *pe, *temb, *st, *mods;
   float *cosT, *sinT, *ids, *tvals;
+  // fp8 mode: quantised block weights, quantised activation rows (xq: LayerNorm output, aq: attention / MLP output)
+  int precision = TD_PRECISION_BF16;
+  char* arena8 = nullptr;
+  std::vector<DoubleW8> dbl8;
+  std::vector<SingleW8> sgl8;
+  uint8_t *xq = nullptr, *aq = nullptr;
+  float *xs = nullptr, *as_ = nullptr;
   // state
   int T = 0, S_img = 0, n_steps = 0;
   bool cond_set = false;
@@ -139,6 +153,38 @@ int gemm2(td_flux* f, hipStream_t s, const bf16_t* A0, const bf16_t* W0, const b
   p.g_A = A1; p.g_W = W1; p.g_bias = b1; p.g_C = C1; p.g_M = M1; p.g_gate = gate1; p.g_res = residual ? C1 : nullptr;
   p.lda = ld_a; p.ldc = ld_c; p.ldr = ld_c; p.N = N; p.K = K; p.act = act;
   return gemm_p(f, s, p);
+}
+
+// fp8 forms of gemm / gemm2: A is e4m3 rows + per-row scales, W an Fp8Mat
+int gemm8(td_flux* f, hipStream_t s, const uint8_t* A, int lda, const float* a_scale, const Fp8Mat& W, const bf16_t* b, bf16_t* C, int ldc,
+          int M, int N, int K, int act = TD_ACT_NONE, const bf16_t* gate = nullptr, const bf16_t* res = nullptr, int ldr = 0,
+          bf16_t* C2 = nullptr, int ldc2 = 0, int act2 = TD_ACT_NONE, int n_split = 0) {
+  TdGemmParams p;
+  p.fp8 = 1; p.A = (const bf16_t*)A; p.lda = lda; p.a_scale = a_scale; p.W = (const bf16_t*)W.q; p.w_scale = W.s;
+  p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
+  p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.n_split = n_split;
+  const int cfg = td_gemm_config_id(M, N, K / 2);
+  TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * M * N * K);
+  return td_gemm_launch(p, s);
+}
+int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, const Fp8Mat& W0, const bf16_t* b0, bf16_t* C0, int M0,
+            const uint8_t* A1, const float* as1, const Fp8Mat& W1, const bf16_t* b1, bf16_t* C1, int M1, int ld_a, int ld_c, int N, int K,
+            int act = TD_ACT_NONE, const bf16_t* gate0 = nullptr, const bf16_t* gate1 = nullptr, bool residual = false) {
+  TdGemmParams p;
+  p.fp8 = 1;
+  p.A = (const bf16_t*)A0; p.a_scale = as0; p.W = (const bf16_t*)W0.q; p.w_scale = W0.s; p.bias = b0; p.C = C0; p.M = M0;
+  p.gate = gate0; p.res = residual ? C0 : nullptr;
+  p.g_A = (const bf16_t*)A1; p.g_a_scale = as1; p.g_W = (const bf16_t*)W1.q; p.g_w_scale = W1.s; p.g_bias = b1; p.g_C = C1; p.g_M = M1;
+  p.g_gate = gate1; p.g_res = residual ? C1 : nullptr;
+  p.lda = ld_a; p.ldc = ld_c; p.ldr = ld_c; p.N = N; p.K = K; p.act = act;
+  const int cfg = td_gemm_config_id(M0 + M1, N, K / 2);
+  TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * (M0 + M1) * N * K);
+  return td_gemm_launch(p, s);
+}
+// per-token quantisation of a bf16 activation matrix into f->aq / f->as_
+int quant_act(td_flux* f, hipStream_t s, const bf16_t* x, int ldx, int rows, int K) {
+  TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
+  return td_quant_rows_fp8_launch(x, ldx, f->aq, K, f->as_, rows, K, s);
 }
 
 int norm_rows(td_flux* f, hipStream_t s, const TdNormParams& p) {
@@ -318,6 +364,7 @@ void td_flux_destroy(td_flux* f) {
   for (hipEvent_t ev : f->ev_pool) (void)hipEventDestroy(ev);
   (void)hipFree(f->arena);
   (void)hipFree(f->ws);
+  if (f->arena8) (void)hipFree(f->arena8);
   delete f;
 }
 
@@ -342,6 +389,65 @@ int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t co
   const Slot& s = f->slots[it->second];
   TD_CHECK_ARG(s.count == count, "td_flux_load_param: '%s' expects %lld elements, got %lld", name, (long long)s.count, (long long)count);
   TD_CHECK_HIP(hipMemcpyAsync(s.ptr, src, (size_t)count * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TD_OK;
+}
+
+// fp8 mode: quantise every block Linear (per output channel, OCP e4m3) from the bf16 arena as it stands NOW -- call
+// after the checkpoint is loaded, and again after reloading parameters.  Embedders, modulation and the final
+// projection stay bf16 (< 0.1 % of the FLOPs; the modulation GEMM runs once per image).
+int td_flux_set_precision(td_flux* f, int precision, void* stream) {
+  TD_CHECK_ARG(f && (precision == TD_PRECISION_BF16 || precision == TD_PRECISION_FP8_E4M3), "td_flux_set_precision: unknown precision %d", precision);
+  if (precision == TD_PRECISION_BF16) { f->precision = precision; return TD_OK; }
+  TD_CHECK_ARG(f->D % 128 == 0 && f->M % 128 == 0, "td_flux_set_precision: fp8 needs inner widths that are multiples of 128");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t D = f->D, M = f->M, L = f->cfg.num_layers, Ls = f->cfg.num_single_layers;
+  const int64_t S = (int64_t)f->max_img + f->max_txt;
+  if (!f->arena8) {
+    auto al = [](int64_t b) { return (b + 255) & ~int64_t(255); };
+    const int64_t per_double = 2 * (al(3 * D * D) + al(D * D) + al(M * D) + al(D * M)) + 2 * (al(3 * D * 4) + al(D * 4) + al(M * 4) + al(D * 4));
+    const int64_t per_single = al((3 * D + M) * D) + al(D * (D + M)) + al((3 * D + M) * 4) + al(D * 4);
+    const int64_t act = al(S * D) + al(S * (D + M)) + 2 * al(S * 4);
+    const int64_t total = L * per_double + Ls * per_single + act;
+    hipError_t e = hipMalloc((void**)&f->arena8, (size_t)total);
+    if (e != hipSuccess) {
+      td_set_error("td_flux_set_precision: hipMalloc of %.2f GiB fp8 arena failed: %s", total / double(1 << 30), hipGetErrorString(e));
+      return TD_ERR_HIP;
+    }
+    int64_t o = 0;
+    auto take = [&](int64_t rows, int64_t K) {
+      Fp8Mat m;
+      m.q = (uint8_t*)(f->arena8 + o); o += al(rows * K);
+      m.s = (float*)(f->arena8 + o); o += al(rows * 4);
+      return m;
+    };
+    f->dbl8.resize(L);
+    f->sgl8.resize(Ls);
+    for (auto& w : f->dbl8) {
+      w.qkv_img = take(3 * D, D); w.qkv_ctx = take(3 * D, D); w.out_img = take(D, D); w.out_ctx = take(D, D);
+      w.ff1_img = take(M, D); w.ff1_ctx = take(M, D); w.ff2_img = take(D, M); w.ff2_ctx = take(D, M);
+    }
+    for (auto& w : f->sgl8) { w.w1 = take(3 * D + M, D); w.w2 = take(D, D + M); }
+    f->xq = (uint8_t*)(f->arena8 + o); o += al(S * D);
+    f->aq = (uint8_t*)(f->arena8 + o); o += al(S * (D + M));
+    f->xs = (float*)(f->arena8 + o); o += al(S * 4);
+    f->as_ = (float*)(f->arena8 + o); o += al(S * 4);
+  }
+  auto qz = [&](const bf16_t* w, const Fp8Mat& m, int64_t rows, int64_t K) {
+    return td_quant_rows_fp8_launch(w, (int)K, m.q, (int)K, m.s, (int)rows, (int)K, s);
+  };
+  for (int i = 0; i < L; ++i) {
+    const DoubleW& w = f->dbl[i];
+    const DoubleW8& q = f->dbl8[i];
+    TD_TRY(qz(w.qkv_img_w, q.qkv_img, 3 * D, D)); TD_TRY(qz(w.qkv_ctx_w, q.qkv_ctx, 3 * D, D));
+    TD_TRY(qz(w.out_img_w, q.out_img, D, D)); TD_TRY(qz(w.out_ctx_w, q.out_ctx, D, D));
+    TD_TRY(qz(w.ff1_img_w, q.ff1_img, M, D)); TD_TRY(qz(w.ff1_ctx_w, q.ff1_ctx, M, D));
+    TD_TRY(qz(w.ff2_img_w, q.ff2_img, D, M)); TD_TRY(qz(w.ff2_ctx_w, q.ff2_ctx, D, M));
+  }
+  for (int i = 0; i < Ls; ++i) {
+    TD_TRY(qz(f->sgl[i].w1, f->sgl8[i].w1, 3 * D + M, D));
+    TD_TRY(qz(f->sgl[i].w2, f->sgl8[i].w2, D, D + M));
+  }
+  f->precision = precision;
   return TD_OK;
 }
 
@@ -457,6 +563,10 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   ap.Q = f->qkv; ap.K = f->qkv + D; ap.V = f->qkv + 2 * D; ap.ldq = ap.ldkv = 3 * D;
   ap.Sq = ap.Skv = S; ap.Hq = ap.Hkv = H; ap.scale = scale; ap.batch = 1;
 
+  // fp8 mode: the LayerNorm-modulate kernel emits e4m3 rows + per-token scales directly; attention / MLP outputs
+  // get a per-token quantisation pass; every block GEMM then runs on the fp8 MFMA path.
+  const bool q8 = f->precision == TD_PRECISION_FP8_E4M3;
+  if (q8) { np.q = f->xq; np.ldq = D; np.q_scale = f->xs; }
   for (int i = 0; i < L; ++i) {
     const DoubleW& w = f->dbl[i];
     const bf16_t* mi = mod + (size_t)i * 12 * D;  // img: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
@@ -464,20 +574,42 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     np.shiftA = mc; np.scaleA = mc + D; np.shiftB = mi; np.scaleB = mi + D;
     TD_TRY(norm_rows(f, s, np));
     bf16_t* xn_img = f->xn + (size_t)T * D;
-    TD_TRY(gemm2(f, s, xn_img, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
-                 f->xn, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
+    if (q8) {
+      const DoubleW8& w8 = f->dbl8[i];
+      TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.qkv_img, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
+                     f->xq, f->xs, w8.qkv_ctx, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
+    } else {
+      TD_TRY(gemm2(f, s, xn_img, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
+                   f->xn, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
+    }
     rp.wqA = w.norm_added_q; rp.wkA = w.norm_added_k; rp.wqB = w.norm_q; rp.wkB = w.norm_k;
     TD_TRY(qk_rope(f, s, rp));
     ap.O = f->attn; ap.ldo = D;
     TD_TRY(attn(f, s, ap));
-    TD_TRY(gemm2(f, s, f->attn + (size_t)T * D, w.out_img_w, w.out_img_b, h_img, Si,
-                 f->attn, w.out_ctx_w, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
+    if (q8) {
+      const DoubleW8& w8 = f->dbl8[i];
+      TD_TRY(quant_act(f, s, f->attn, D, S, D));
+      TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * D, f->as_ + T, w8.out_img, w.out_img_b, h_img, Si,
+                     f->aq, f->as_, w8.out_ctx, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
+    } else {
+      TD_TRY(gemm2(f, s, f->attn + (size_t)T * D, w.out_img_w, w.out_img_b, h_img, Si,
+                   f->attn, w.out_ctx_w, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
+    }
     np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
     TD_TRY(norm_rows(f, s, np));
-    TD_TRY(gemm2(f, s, xn_img, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
-                 f->xn, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
-    TD_TRY(gemm2(f, s, f->mlp + (size_t)T * M, w.ff2_img_w, w.ff2_img_b, h_img, Si,
-                 f->mlp, w.ff2_ctx_w, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
+    if (q8) {
+      const DoubleW8& w8 = f->dbl8[i];
+      TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.ff1_img, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
+                     f->xq, f->xs, w8.ff1_ctx, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
+      TD_TRY(quant_act(f, s, f->mlp, M, S, M));
+      TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * M, f->as_ + T, w8.ff2_img, w.ff2_img_b, h_img, Si,
+                     f->aq, f->as_, w8.ff2_ctx, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
+    } else {
+      TD_TRY(gemm2(f, s, xn_img, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
+                   f->xn, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
+      TD_TRY(gemm2(f, s, f->mlp + (size_t)T * M, w.ff2_img_w, w.ff2_img_b, h_img, Si,
+                   f->mlp, w.ff2_ctx_w, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
+    }
   }
 
   const bool fused_split = (3 * D) % 256 == 0;
@@ -486,7 +618,18 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     const bf16_t* ms = mod + (size_t)L * 12 * D + (size_t)i * 3 * D;  // shift, scale, gate
     np.shiftA = np.shiftB = ms; np.scaleA = np.scaleB = ms + D;
     TD_TRY(norm_rows(f, s, np));
-    if (fused_split) {
+    if (q8) {
+      const SingleW8& w8 = f->sgl8[i];
+      if (fused_split) {
+        TD_TRY(gemm8(f, s, f->xq, D, f->xs, w8.w1, w.b1, f->qkv, 3 * D, S, 3 * D + M, D, TD_ACT_NONE, nullptr, nullptr, 0,
+                     f->cat + D, D + M, TD_ACT_GELU_TANH, 3 * D));
+      } else {
+        Fp8Mat wa = w8.w1, wb = w8.w1;
+        wb.q += (size_t)3 * D * D; wb.s += 3 * D;
+        TD_TRY(gemm8(f, s, f->xq, D, f->xs, wa, w.b1, f->qkv, 3 * D, S, 3 * D, D));
+        TD_TRY(gemm8(f, s, f->xq, D, f->xs, wb, w.b1 + 3 * D, f->cat + D, D + M, S, M, D, TD_ACT_GELU_TANH));
+      }
+    } else if (fused_split) {
       TdGemmParams gp;
       gp.A = f->xn; gp.lda = D; gp.W = w.w1; gp.bias = w.b1; gp.M = S; gp.N = 3 * D + M; gp.K = D;
       gp.C = f->qkv; gp.ldc = 3 * D; gp.act = TD_ACT_NONE;
@@ -500,12 +643,18 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     TD_TRY(qk_rope(f, s, rp));
     ap.O = f->cat; ap.ldo = D + M;
     TD_TRY(attn(f, s, ap));
-    TD_TRY(gemm(f, s, f->cat, D + M, w.w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
+    if (q8) {
+      TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M));
+      TD_TRY(gemm8(f, s, f->aq, D + M, f->as_, f->sgl8[i].w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
+    } else {
+      TD_TRY(gemm(f, s, f->cat, D + M, w.w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
+    }
   }
 
   // AdaLayerNormContinuous: chunk order (scale, shift); image rows only
   const bf16_t* mf = mod + (size_t)L * 12 * D + (size_t)Ls * 3 * D;
   TdNormParams nf = np;
+  nf.q = nullptr;   // the final projection stays bf16
   nf.x = h_img; nf.y = f->xn; nf.rows = Si; nf.split = 0;
   nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
   TD_TRY(norm_rows(f, s, nf));

@@ -124,6 +124,14 @@ class FluxTransformer2DModel:
         _hip.check(self._L.td_flux_init_random(self._h, seed, std, _hip.stream_ptr()))
         return self
 
+    def set_precision(self, precision: str = "bf16"):
+        """"bf16" (default) or "fp8": e4m3 operands for every block GEMM (weights quantised per output channel from the
+        parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly)."""
+        code = {"bf16": 0, "bfloat16": 0, "fp8": 1, "fp8_e4m3": 1, "float8_e4m3fn": 1}[str(precision).replace("torch.", "")]
+        _hip.check(self._L.td_flux_set_precision(self._h, code, _hip.stream_ptr()))
+        self.precision = "fp8" if code else "bf16"
+        return self
+
     # ---- conditioning / schedule ----------------------------------------------------------------------
     def set_condition(self, prompt_embeds, pooled, img_ids, txt_ids=None):
         assert prompt_embeds.dim() == 2 and pooled.dim() == 1, "one prompt per call: [T,joint], [pooled]"
