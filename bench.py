@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip the per-launch HIP-event trace (roofline leg)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="independent images advanced concurrently per rank (engine contexts on separate streams); a step = this many images")
     ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
                     help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path")
     a = ap.parse_args()
@@ -136,17 +138,19 @@ def main():
 
     # synthetic inputs (SURVEY.md 8d cfg 2), seed + rank as the reference drivers do
     g = torch.Generator().manual_seed(42 + rank)
-    prompt_embeds = (0.1 * torch.randn(1, T_TXT, 4096, generator=g)).bfloat16().cuda()
-    pooled = torch.randn(1, 768, generator=g).bfloat16().cuda()
-    raw = torch.randn(1, 16, HEIGHT // 8, WIDTH // 8, generator=g).bfloat16().cuda()
+    G = max(1, a.in_flight)
+    pipe.images_in_flight = G
+    prompt_embeds = (0.1 * torch.randn(G, T_TXT, 4096, generator=g)).bfloat16().cuda()     # G different prompts
+    pooled = torch.randn(G, 768, generator=g).bfloat16().cuda()
+    raw = torch.randn(G, 16, HEIGHT // 8, WIDTH // 8, generator=g).bfloat16().cuda()
     from thinkdiff import _hip
-    packed = _hip.flux_pack_latents(raw[0])[None]
+    packed = torch.stack([_hip.flux_pack_latents(raw[i]) for i in range(G)])
     torch.cuda.synchronize()
 
-    def one_image():
-        return pipe(prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled, num_images_per_prompt=1,
+    def one_image(n=G):
+        return pipe(prompt_embeds=prompt_embeds[:n], pooled_prompt_embeds=pooled[:n], num_images_per_prompt=1,
                     height=HEIGHT, width=WIDTH, num_inference_steps=NUM_STEPS, guidance_scale=GUIDANCE,
-                    latents=packed.clone(), output_type="pil").images
+                    latents=packed[:n].clone(), output_type="pil").images
 
     def fence():
         torch.cuda.synchronize()
@@ -157,18 +161,33 @@ def main():
     for _ in range(a.warmup):
         out = one_image()
     fence()
-    # The per-launch HIP-event trace (roofline leg) brackets every kernel of the LAST timed image on the
-    # launch stream; tracing all K images would cost ~4 % of `value` (two event records per launch).
     trace = not a.no_trace
     t0 = time.perf_counter()
     for i in range(a.steps):
-        if trace and i == a.steps - 1:
-            tr.trace_begin(NUM_STEPS * 460 + 64)
+        if trace and G == 1 and i == a.steps - 1:
+            # one image in flight: the per-launch HIP-event trace brackets every kernel of the LAST timed image
+            # (tracing all K would cost ~4 % of `value`: two event records per launch)
+            tr.trace_begin(NUM_STEPS * 520 + 64)
         out = one_image()
     fence()
     elapsed = time.perf_counter() - t0
-    cats = tr.trace_end() if trace else None
-    assert out[0].size == (WIDTH, HEIGHT) and out[0].mode == "RGB", "pipeline did not return a decoded image"
+    cats = tr.trace_end() if (trace and G == 1) else None
+    assert len(out) == G and out[0].size == (WIDTH, HEIGHT) and out[0].mode == "RGB", "pipeline did not return decoded images"
+    single = None
+    if G > 1 and rank == 0:
+        # With several images in flight the kernels of different images overlap on the chip, so a per-launch event
+        # interval is no longer that kernel's own duration: the roofline leg (and the one-image-at-a-time rate) are
+        # taken on images run alone, right after the timed region, same process, same weights and inputs.
+        one_image(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_image(1)
+        torch.cuda.synchronize()
+        single = time.perf_counter() - t1
+        if trace:
+            tr.trace_begin(NUM_STEPS * 520 + 64)
+            one_image(1)
+            cats = tr.trace_end()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -177,7 +196,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        value = world * a.steps / elapsed
+        value = world * a.steps * G / elapsed
         flops_img = NUM_STEPS * flux_flops_per_forward(4096, T_TXT)
         res = {
             "metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X",
@@ -188,14 +207,17 @@ def main():
             "config": {
                 "workload": ("BASELINE config 2: ThinkDiff-CLIP single image+text, FLUX.1-dev shape (11.9 B params, seeded "
                              "random init), 1024x1024, 28 Euler steps, T_txt=193 (65 aligner + 128 T5), joint S=4289, "
-                             "guidance 3.5; step = one image per rank, from HBM-resident prompt_embeds/pooled/latents through the 28-step "
+                             "guidance 3.5; step = `images_per_rank_per_step` independent images per rank (different prompts and latents, "
+                             "advanced concurrently on separate streams over one set of weights), each from HBM-resident prompt_embeds/pooled/latents through the 28-step "
                              "denoise loop, VAE decode (FLUX.1-dev VAE shape, seeded random init) and uint8 conversion to a host "
                              "PIL image -- the reference driver's diffusion_pipe(...).images[0]"),
-                "precision": a.precision, "images_per_rank_per_step": 1, "parallelism": f"dp{world} (independent images, seed+rank)",
+                "precision": a.precision, "images_per_rank_per_step": G, "parallelism": f"dp{world} (independent images, seed+rank)",
                 "algorithmic_pflop_per_image": flops_img / 1e15,
             },
-            "whole_step_tflops_per_gpu": flops_img / (elapsed / a.steps) / 1e12,
+            "whole_step_tflops_per_gpu": flops_img * G / (elapsed / a.steps) / 1e12,
         }
+        if single is not None:
+            res["one_image_in_flight"] = {"value": 1.0 / single, "unit": "images/s/GPU", "ms_per_image": single * 1e3}
         if cats:
             kern = {"gemm_256x256": "td_gemm_bf16_nt_kernel<8,4>", "gemm_288x192": "td_gemm_bf16_nt_kernel<9,3>"}
             dom = max(kern, key=lambda k: cats[k]["ms"])      # the GEMM tile variant with the most device time
@@ -213,7 +235,9 @@ def main():
             # inside the timed process): profiles/r*_hbm_traffic.json, made by tools/pmc_traffic.py
             if a.precision == "bf16":
                 res["roofline"].update(_pmc_traffic(kern[dom]))
-            res["roofline"]["sampled"] = "every launch of the kernel in the last image of the timed region (HIP events on the launch stream)"
+            res["roofline"]["sampled"] = ("every launch of the kernel in the last image of the timed region (HIP events on the launch stream)" if G == 1 else
+                                          "every launch of the kernel in one image run alone right after the timed region (HIP events on the launch stream); "
+                                          "inside the timed region kernels of the images in flight overlap, so per-launch intervals are not kernel durations")
             res["kernel_ms_per_image"] = {k: v["ms"] for k, v in cats.items()}
             at = cats["attention"]
             res["attention_tflops"] = at["flops"] / (at["ms"] * 1e-3) / 1e12 if at["ms"] > 0 else 0.0

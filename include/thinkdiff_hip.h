@@ -157,6 +157,13 @@ int td_flux_num_params(const td_flux* f);
 int td_flux_param_info(const td_flux* f, int idx, char* name_buf, int buf_len, int64_t* count);
 /* copy one parameter (device bf16, `count` elements) into the engine's fused weight arena */
 int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t count, void* stream);
+/* A second context over the same weights (own workspace, conditioning, timestep schedule): independent images in flight on
+ * separate streams fill the tails of each other's kernels (a 1024^2 step's grids are 1.6 - 3.2 rounds of the 256 CUs).
+ * The parent must outlive its forks; parameters and precision are the parent's.  Destroy with td_flux_destroy. */
+int td_flux_fork(td_flux* parent, td_flux** out);
+/* td_flux_denoise for `count` contexts (a parent and its forks), advanced step by step, context k on streams[k]. */
+int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, const float* sigmas, int n, void* const* streams);
+
 /* Operand precision of the block GEMMs.  TD_PRECISION_FP8_E4M3 quantises every double-/single-stream Linear weight per
  * output channel from the parameters as loaded NOW (call after loading; call again after reloading) and runs those GEMMs on
  * the fp8 MFMA path with per-token dynamic activation scales (BASELINE config 5).  Accumulation, epilogues, attention,

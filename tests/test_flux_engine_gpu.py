@@ -114,3 +114,27 @@ def test_fp8_mode_matches_fp8_oracle(hip, layers, singles, h2, w2, T):
     assert e88 < 3e-2
     assert e816 < 0.15 and abs(e816 - o816) < 0.5 * o816 + 1e-2
     assert torch.equal(back, out16)            # switching back restores the bf16 path bit for bit
+
+
+def test_images_in_flight_are_bit_identical_to_sequential(hip):
+    """FluxPipelineRewritePrompt with 3 prompts: two images in flight on forked contexts / separate streams produce
+    exactly the latents of the one-at-a-time loop (contexts share weights only)."""
+    from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
+    from thinkdiff.models.flux_transformer import FluxTransformerConfig
+    cfg = FluxTransformerConfig(num_layers=1, num_single_layers=2, num_attention_heads=4, joint_attention_dim=512, pooled_projection_dim=256)
+    pipe = FluxPipelineRewritePrompt.from_random(cfg, seed=3, with_vae=False, max_img_tokens=256, max_txt_tokens=64, max_steps=8)
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(3, 40, 512, generator=g).bfloat16().cuda()
+    pool = torch.randn(3, 256, generator=g).bfloat16().cuda()
+    lat = torch.randn(3, 16 * 16, 64, generator=g).bfloat16().cuda()
+    outs = {}
+    for prec in ("bf16", "fp8"):
+        pipe.transformer.set_precision(prec)
+        for G in (1, 2, 3):
+            pipe.images_in_flight = G
+            outs[prec, G] = pipe(prompt_embeds=pe, pooled_prompt_embeds=pool, height=256, width=256, num_inference_steps=4,
+                                 guidance_scale=3.5, latents=lat.clone(), output_type="latent").images.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[prec, 1], outs[prec, 2]) and torch.equal(outs[prec, 1], outs[prec, 3])
+        assert not torch.equal(outs[prec, 1][0], outs[prec, 1][1])
+    assert not torch.equal(outs["bf16", 1], outs["fp8", 1])

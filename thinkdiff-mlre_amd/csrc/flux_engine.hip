@@ -81,8 +81,11 @@ struct td_flux {
   char* arena8 = nullptr;
   std::vector<DoubleW8> dbl8;
   std::vector<SingleW8> sgl8;
-  uint8_t *xq = nullptr, *aq = nullptr;
+  uint8_t *xq = nullptr, *aq = nullptr;     // per-context, part of the workspace
   float *xs = nullptr, *as_ = nullptr;
+  // a forked context (td_flux_fork) shares the parent's weights (bf16 arena, fp8 arena, precision) and owns its
+  // workspace, conditioning and schedule: several images in flight on separate streams fill each other's kernel tails
+  td_flux* parent = nullptr;
   // state
   int T = 0, S_img = 0, n_steps = 0;
   bool cond_set = false;
@@ -219,6 +222,43 @@ int gemm_big_n(td_flux* f, hipStream_t s, const bf16_t* A, int lda, const bf16_t
     if (_rc != 0) return _rc; \
   } while (0)
 
+// per-context activation workspace (one allocation)
+int alloc_workspace(td_flux* f) {
+  // ---- activation workspace -----------------------------------------------------------------------
+  const TdFluxConfig* cfg = &f->cfg;
+  const int64_t D = f->D, M = f->M;
+  const int max_img_tokens = f->max_img, max_txt_tokens = f->max_txt;
+  const int64_t S = (int64_t)max_img_tokens + max_txt_tokens;
+  const int64_t n = f->max_steps;
+  struct Req { void** p; int64_t bytes; };
+  std::vector<Req> reqs = {
+      {(void**)&f->h, S * D * 2}, {(void**)&f->xn, S * D * 2}, {(void**)&f->qkv, S * 3 * D * 2},
+      {(void**)&f->attn, S * D * 2}, {(void**)&f->mlp, S * M * 2}, {(void**)&f->cat, S * (D + M) * 2},
+      {(void**)&f->ctx, (int64_t)max_txt_tokens * D * 2}, {(void**)&f->vout, (int64_t)max_img_tokens * cfg->in_channels * 2},
+      {(void**)&f->tproj, n * 256 * 2}, {(void**)&f->tmid, n * D * 2}, {(void**)&f->te, n * D * 2},
+      {(void**)&f->gproj, 256 * 2}, {(void**)&f->gmid, (int64_t)D * 2}, {(void**)&f->ge, (int64_t)D * 2},
+      {(void**)&f->pmid, (int64_t)D * 2}, {(void**)&f->pe, (int64_t)D * 2},
+      {(void**)&f->temb, n * D * 2}, {(void**)&f->st, n * D * 2}, {(void**)&f->mods, n * (int64_t)f->NMOD * 2},
+      {(void**)&f->cosT, S * 128 * 4}, {(void**)&f->sinT, S * 128 * 4}, {(void**)&f->ids, S * 3 * 4},
+      {(void**)&f->tvals, (n + 1) * 4},
+      {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
+  };
+  int64_t total = 0;
+  for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
+  hipError_t e = hipMalloc((void**)&f->ws, (size_t)total);
+  if (e != hipSuccess) {
+    td_set_error("td_flux: hipMalloc of %.2f GiB workspace failed: %s", total / double(1 << 30), hipGetErrorString(e));
+    return TD_ERR_HIP;
+  }
+  (void)hipMemset(f->ws, 0, (size_t)total);
+  int64_t o = 0;
+  for (auto& r : reqs) {
+    *r.p = f->ws + o;
+    o += (r.bytes + 255) & ~int64_t(255);
+  }
+  return TD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,35 +365,10 @@ int td_flux_create(const TdFluxConfig* cfg, int max_img_tokens, int max_txt_toke
   add_linear(f, "norm_out.linear", f->mod_w, f->mod_b, (int64_t)L * 12 * D + (int64_t)Ls * 3 * D, 2 * D, D);
   add_linear(f, "proj_out", f->proj_w, f->proj_b, 0, cfg->in_channels, D);
 
-  // ---- activation workspace -----------------------------------------------------------------------
-  const int64_t S = (int64_t)max_img_tokens + max_txt_tokens;
-  const int64_t n = max_steps;
-  struct Req { void** p; int64_t bytes; };
-  std::vector<Req> reqs = {
-      {(void**)&f->h, S * D * 2}, {(void**)&f->xn, S * D * 2}, {(void**)&f->qkv, S * 3 * D * 2},
-      {(void**)&f->attn, S * D * 2}, {(void**)&f->mlp, S * M * 2}, {(void**)&f->cat, S * (D + M) * 2},
-      {(void**)&f->ctx, (int64_t)max_txt_tokens * D * 2}, {(void**)&f->vout, (int64_t)max_img_tokens * cfg->in_channels * 2},
-      {(void**)&f->tproj, n * 256 * 2}, {(void**)&f->tmid, n * D * 2}, {(void**)&f->te, n * D * 2},
-      {(void**)&f->gproj, 256 * 2}, {(void**)&f->gmid, (int64_t)D * 2}, {(void**)&f->ge, (int64_t)D * 2},
-      {(void**)&f->pmid, (int64_t)D * 2}, {(void**)&f->pe, (int64_t)D * 2},
-      {(void**)&f->temb, n * D * 2}, {(void**)&f->st, n * D * 2}, {(void**)&f->mods, n * (int64_t)f->NMOD * 2},
-      {(void**)&f->cosT, S * 128 * 4}, {(void**)&f->sinT, S * 128 * 4}, {(void**)&f->ids, S * 3 * 4},
-      {(void**)&f->tvals, (n + 1) * 4},
-  };
-  int64_t total = 0;
-  for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
-  e = hipMalloc((void**)&f->ws, (size_t)total);
-  if (e != hipSuccess) {
-    td_set_error("td_flux_create: hipMalloc of %.2f GiB workspace failed: %s", total / double(1 << 30), hipGetErrorString(e));
+  if (int rc = alloc_workspace(f)) {
     (void)hipFree(f->arena);
     delete f;
-    return TD_ERR_HIP;
-  }
-  (void)hipMemset(f->ws, 0, (size_t)total);
-  int64_t o = 0;
-  for (auto& r : reqs) {
-    *r.p = f->ws + o;
-    o += (r.bytes + 255) & ~int64_t(255);
+    return rc;
   }
   *out = f;
   return TD_OK;
@@ -362,10 +377,27 @@ int td_flux_create(const TdFluxConfig* cfg, int max_img_tokens, int max_txt_toke
 void td_flux_destroy(td_flux* f) {
   if (!f) return;
   for (hipEvent_t ev : f->ev_pool) (void)hipEventDestroy(ev);
-  (void)hipFree(f->arena);
+  if (!f->parent) {
+    (void)hipFree(f->arena);
+    if (f->arena8) (void)hipFree(f->arena8);
+  }
   (void)hipFree(f->ws);
-  if (f->arena8) (void)hipFree(f->arena8);
   delete f;
+}
+
+// A second context over the same weights: own workspace / conditioning / timestep schedule, so that independent images
+// can be in flight on separate streams.  The parent must outlive its forks; precision and parameters are the parent's.
+int td_flux_fork(td_flux* src, td_flux** out) {
+  TD_CHECK_ARG(src && out, "td_flux_fork: null argument");
+  td_flux* root = src->parent ? src->parent : src;
+  td_flux* f = new td_flux(*root);
+  f->parent = root;
+  f->ws = nullptr;
+  f->ev_pool.clear(); f->trace.clear(); f->tracing = false;
+  f->T = f->S_img = f->n_steps = 0; f->cond_set = false;
+  if (int rc = alloc_workspace(f)) { delete f; return rc; }
+  *out = f;
+  return TD_OK;
 }
 
 int64_t td_flux_param_elems(const td_flux* f) { return f ? f->arena_elems : 0; }
@@ -397,17 +429,16 @@ int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t co
 // projection stay bf16 (< 0.1 % of the FLOPs; the modulation GEMM runs once per image).
 int td_flux_set_precision(td_flux* f, int precision, void* stream) {
   TD_CHECK_ARG(f && (precision == TD_PRECISION_BF16 || precision == TD_PRECISION_FP8_E4M3), "td_flux_set_precision: unknown precision %d", precision);
+  TD_CHECK_ARG(!f->parent, "td_flux_set_precision: set the precision on the parent context (forks follow it)");
   if (precision == TD_PRECISION_BF16) { f->precision = precision; return TD_OK; }
   TD_CHECK_ARG(f->D % 128 == 0 && f->M % 128 == 0, "td_flux_set_precision: fp8 needs inner widths that are multiples of 128");
   hipStream_t s = (hipStream_t)stream;
   const int64_t D = f->D, M = f->M, L = f->cfg.num_layers, Ls = f->cfg.num_single_layers;
-  const int64_t S = (int64_t)f->max_img + f->max_txt;
   if (!f->arena8) {
     auto al = [](int64_t b) { return (b + 255) & ~int64_t(255); };
     const int64_t per_double = 2 * (al(3 * D * D) + al(D * D) + al(M * D) + al(D * M)) + 2 * (al(3 * D * 4) + al(D * 4) + al(M * 4) + al(D * 4));
     const int64_t per_single = al((3 * D + M) * D) + al(D * (D + M)) + al((3 * D + M) * 4) + al(D * 4);
-    const int64_t act = al(S * D) + al(S * (D + M)) + 2 * al(S * 4);
-    const int64_t total = L * per_double + Ls * per_single + act;
+    const int64_t total = L * per_double + Ls * per_single;
     hipError_t e = hipMalloc((void**)&f->arena8, (size_t)total);
     if (e != hipSuccess) {
       td_set_error("td_flux_set_precision: hipMalloc of %.2f GiB fp8 arena failed: %s", total / double(1 << 30), hipGetErrorString(e));
@@ -427,10 +458,6 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream) {
       w.ff1_img = take(M, D); w.ff1_ctx = take(M, D); w.ff2_img = take(D, M); w.ff2_ctx = take(D, M);
     }
     for (auto& w : f->sgl8) { w.w1 = take(3 * D + M, D); w.w2 = take(D, D + M); }
-    f->xq = (uint8_t*)(f->arena8 + o); o += al(S * D);
-    f->aq = (uint8_t*)(f->arena8 + o); o += al(S * (D + M));
-    f->xs = (float*)(f->arena8 + o); o += al(S * 4);
-    f->as_ = (float*)(f->arena8 + o); o += al(S * 4);
   }
   auto qz = [&](const bf16_t* w, const Fp8Mat& m, int64_t rows, int64_t K) {
     return td_quant_rows_fp8_launch(w, (int)K, m.q, (int)K, m.s, (int)rows, (int)K, s);
@@ -565,7 +592,8 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
 
   // fp8 mode: the LayerNorm-modulate kernel emits e4m3 rows + per-token scales directly; attention / MLP outputs
   // get a per-token quantisation pass; every block GEMM then runs on the fp8 MFMA path.
-  const bool q8 = f->precision == TD_PRECISION_FP8_E4M3;
+  const td_flux* root = f->parent ? f->parent : f;   // weights and precision live in the parent context
+  const bool q8 = root->precision == TD_PRECISION_FP8_E4M3;
   if (q8) { np.q = f->xq; np.ldq = D; np.q_scale = f->xs; }
   for (int i = 0; i < L; ++i) {
     const DoubleW& w = f->dbl[i];
@@ -575,7 +603,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     TD_TRY(norm_rows(f, s, np));
     bf16_t* xn_img = f->xn + (size_t)T * D;
     if (q8) {
-      const DoubleW8& w8 = f->dbl8[i];
+      const DoubleW8& w8 = root->dbl8[i];
       TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.qkv_img, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
                      f->xq, f->xs, w8.qkv_ctx, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
     } else {
@@ -587,7 +615,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     ap.O = f->attn; ap.ldo = D;
     TD_TRY(attn(f, s, ap));
     if (q8) {
-      const DoubleW8& w8 = f->dbl8[i];
+      const DoubleW8& w8 = root->dbl8[i];
       TD_TRY(quant_act(f, s, f->attn, D, S, D));
       TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * D, f->as_ + T, w8.out_img, w.out_img_b, h_img, Si,
                      f->aq, f->as_, w8.out_ctx, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
@@ -598,7 +626,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
     TD_TRY(norm_rows(f, s, np));
     if (q8) {
-      const DoubleW8& w8 = f->dbl8[i];
+      const DoubleW8& w8 = root->dbl8[i];
       TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.ff1_img, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
                      f->xq, f->xs, w8.ff1_ctx, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
       TD_TRY(quant_act(f, s, f->mlp, M, S, M));
@@ -619,7 +647,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     np.shiftA = np.shiftB = ms; np.scaleA = np.scaleB = ms + D;
     TD_TRY(norm_rows(f, s, np));
     if (q8) {
-      const SingleW8& w8 = f->sgl8[i];
+      const SingleW8& w8 = root->sgl8[i];
       if (fused_split) {
         TD_TRY(gemm8(f, s, f->xq, D, f->xs, w8.w1, w.b1, f->qkv, 3 * D, S, 3 * D + M, D, TD_ACT_NONE, nullptr, nullptr, 0,
                      f->cat + D, D + M, TD_ACT_GELU_TANH, 3 * D));
@@ -645,7 +673,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     TD_TRY(attn(f, s, ap));
     if (q8) {
       TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M));
-      TD_TRY(gemm8(f, s, f->aq, D + M, f->as_, f->sgl8[i].w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
+      TD_TRY(gemm8(f, s, f->aq, D + M, f->as_, root->sgl8[i].w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
     } else {
       TD_TRY(gemm(f, s, f->cat, D + M, w.w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
     }
@@ -700,6 +728,21 @@ int td_flux_denoise(td_flux* f, void* latents, const float* sigmas, int n, void*
     TD_TRY(td_flux_forward(f, latents, i, f->vout, stream));
     TD_TRY(td_euler_step_launch((bf16_t*)latents, f->vout, sigmas[i + 1] - sigmas[i], (long long)f->S_img * f->cfg.in_channels, (hipStream_t)stream));
   }
+  return TD_OK;
+}
+
+// Several independent images in flight: contexts fs[k] (a parent and its forks) advance step by step, each on its own
+// stream, so the tail of one image's kernels (grids of 1.6 - 3.2 rounds of the 256 CUs) is filled by the other's.
+int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, const float* sigmas, int n, void* const* streams) {
+  TD_CHECK_ARG(fs && latents && sigmas && streams && count > 0, "td_flux_denoise_multi: null argument");
+  for (int k = 0; k < count; ++k)
+    TD_CHECK_ARG(fs[k] && latents[k] && n > 0 && n <= fs[k]->n_steps, "td_flux_denoise_multi: context %d is not prepared for %d steps", k, n);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < count; ++k) {
+      td_flux* f = fs[k];
+      TD_TRY(td_flux_forward(f, latents[k], i, f->vout, streams[k]));
+      TD_TRY(td_euler_step_launch((bf16_t*)latents[k], f->vout, sigmas[i + 1] - sigmas[i], (long long)f->S_img * f->cfg.in_channels, (hipStream_t)streams[k]));
+    }
   return TD_OK;
 }
 

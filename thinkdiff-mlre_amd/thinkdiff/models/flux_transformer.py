@@ -71,6 +71,28 @@ class FluxTransformer2DModel:
         if h:
             self._L.td_flux_destroy(h)
 
+    def fork(self) -> "FluxTransformer2DModel":
+        """A second context over the same weights (own workspace / conditioning / schedule) for images in flight on
+        another stream.  Keeps a reference to the parent, which owns the weights and the precision setting."""
+        child = object.__new__(type(self))
+        child.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_h"})
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(self._L.td_flux_fork(self._h, ctypes.byref(h)))
+        child._h, child._parent, child._n_steps = h, self, 0
+        return child
+
+    @staticmethod
+    def denoise_multi(contexts, latents, sigmas: Sequence[float], streams):
+        """td_flux_denoise for several prepared contexts at once, context k on streams[k] (torch.cuda.Stream)."""
+        n, c = len(sigmas) - 1, len(contexts)
+        arr = (ctypes.c_float * (n + 1))(*[float(s) for s in sigmas])
+        hs = (ctypes.c_void_p * c)(*[m._h.value for m in contexts])
+        ls = (ctypes.c_void_p * c)(*[x.data_ptr() for x in latents])
+        ss = (ctypes.c_void_p * c)(*[st.cuda_stream for st in streams])
+        _hip.check(contexts[0]._L.td_flux_denoise_multi(hs, ls, c, ctypes.cast(arr, ctypes.c_void_p), n, ss))
+        return latents
+
     # ---- parameters ---------------------------------------------------------------------------------
     def param_table(self) -> Dict[str, int]:
         n = self._L.td_flux_num_params(self._h)
