@@ -142,3 +142,38 @@ def test_linear_tile_288x192(hip, M, N, K):
     hip.linear_grouped2(x.cuda(), w.cuda(), b.cuda(), y, None, None, None, None, act=1, tile_cfg=3)
     torch.cuda.synchronize()
     _close(y, _ref_linear(x, w, b, act=1), 2.0 ** -6)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 3584, 18944), (1, 4608, 3584), (2, 152064, 256), (3, 1024, 3072), (5, 40, 1408), (8, 3072, 768), (1, 8, 64)])
+@pytest.mark.parametrize("mode", ["bias", "act", "gate_res", "none"])
+def test_skinny_m_weight_stream_kernel(hip, M, N, K, mode):
+    """M <= 8 routes to csrc/gemv_bf16.hip (td_gemv_bf16_kernel): same epilogue semantics as the tile kernel."""
+    g = torch.Generator().manual_seed(M * 11 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16() if mode != "none" else None
+    gate = torch.randn(N, generator=g).bfloat16() if mode == "gate_res" else None
+    res = torch.randn(M, N, generator=g).bfloat16() if mode == "gate_res" else None
+    act = 1 if mode == "act" else 0
+    y = hip.linear(x.cuda(), w.cuda(), None if b is None else b.cuda(), act=act,
+                   gate=None if gate is None else gate.cuda(), res=None if res is None else res.cuda())
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(x, w, b, act=act, gate=gate, res=res))
+
+
+def test_skinny_m_split_output_and_strided_rows(hip):
+    """The Qwen2 decode form: q -> scratch, k|v -> cache rows (split output), x rows with a stride."""
+    M, K, n_split, N = 2, 512, 1024, 1536
+    g = torch.Generator().manual_seed(5)
+    xbuf = torch.randn(M, K + 64, generator=g).bfloat16().cuda()
+    x = xbuf[:, :K]
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    y0 = torch.zeros(M, n_split, dtype=torch.bfloat16, device="cuda")
+    y1 = torch.zeros(M, N - n_split + 32, dtype=torch.bfloat16, device="cuda")
+    hip.linear_split(x, w, b, y0, 0, y1[:, :N - n_split], 3, n_split)
+    torch.cuda.synchronize()
+    ref = _ref_linear(x.cpu(), w.cpu(), b.cpu())
+    _close(y0, ref[:, :n_split])
+    _close(y1[:, :N - n_split], torch.nn.functional.silu(ref[:, n_split:].float()).bfloat16())
+    assert not y1[:, N - n_split:].any()

@@ -1,0 +1,127 @@
+// Skinny-M Linear for gfx950: y[M<=8, N] = epilogue(x[M,K] . W[N,K]^T), the weight-streaming case of the hot path --
+// KV-cached Qwen2-VL decode (one token against 7.6 B parameters: SURVEY.md 8a row A7, HBM roofline), the pooled / timestep
+// embedders of FLUX, lm_head.  The MFMA tile kernel launches N/256 workgroups here (14 for down_proj) and leaves the
+// chip idle; this kernel is a plain HBM stream:
+//   * a workgroup (4 waves) owns 4 consecutive output columns = 4 weight rows; its 256 threads stride the rows' 16-byte
+//     chunks, so every wave-level load is a fully coalesced 1 KiB line run; loads are non-temporal (weights are read once);
+//   * two chunk-columns are in flight per thread (8 weight loads + the matching x chunks, which hit L2);
+//   * bf16 pairs go straight into v_dot2c_f32_bf16 (fp32 accumulate, no unpacking);
+//   * wave shuffle + LDS cross-wave reduction, then the same epilogue semantics and bf16 rounding points as the tile kernel
+//     (bias, activation, gate, residual, split output).
+#include "td_common.h"
+#include "td_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ float dot8(const u32x4_t& a, const u32x4_t& b, float acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // copy the elements out first: __builtin_bit_cast applied directly to a vector-element lvalue reads element 0 (hipcc 7.2)
+    const unsigned ua = a[q], ub = b[q];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ua), __builtin_bit_cast(bf16x2_t, ub), acc, false);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float act_rt(int act, float x) {
+  switch (act) {
+    case TD_ACT_GELU_TANH: return gelu_tanh_f(x);
+    case TD_ACT_GELU_ERF: return gelu_erf_f(x);
+    case TD_ACT_SILU: return silu_f(x);
+    case TD_ACT_QUICK_GELU: return quick_gelu_f(x);
+    default: return x;
+  }
+}
+
+constexpr int R = 4;          // weight rows (output columns) per workgroup
+constexpr int THREADS = 256;
+
+template <int MR>
+__global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParams p) {
+  __shared__ float red[THREADS / 64][R][MR];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n0 = blockIdx.x * R;
+  const int nchunk = p.K >> 3;
+  const u32x4_t* wp[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) wp[r] = (const u32x4_t*)(p.W + (size_t)min(n0 + r, p.N - 1) * p.K);
+  const u32x4_t* xp[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) xp[m] = (const u32x4_t*)(p.A + (size_t)min(m, p.M - 1) * p.lda);
+
+  float acc[R][MR];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
+
+  int c = tid;
+  for (; c + THREADS < nchunk; c += 2 * THREADS) {
+    u32x4_t w0[R], w1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      w0[r] = __builtin_nontemporal_load(wp[r] + c);
+      w1[r] = __builtin_nontemporal_load(wp[r] + c + THREADS);
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const u32x4_t x0 = xp[m][c], x1 = xp[m][c + THREADS];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r][m] = dot8(w1[r], x1, dot8(w0[r], x0, acc[r][m]));
+    }
+  }
+  if (c < nchunk) {
+    u32x4_t w0[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w0[r] = __builtin_nontemporal_load(wp[r] + c);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const u32x4_t x0 = xp[m][c];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r][m] = dot8(w0[r], x0, acc[r][m]);
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float v = wave_sum(acc[r][m]);
+      if (lane == 0) red[wid][r][m] = v;
+    }
+  __syncthreads();
+  if (tid >= R * MR) return;
+  const int r = tid / MR, m = tid % MR;
+  const int n = n0 + r;
+  if (n >= p.N || m >= p.M) return;
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) v += red[w][r][m];
+  // epilogue: the tile kernel's semantics and rounding points (Linear output, activation, gate, residual each round)
+  const bool second = p.C2 != nullptr && n >= p.n_split;
+  const int act = second ? p.act2 : p.act;
+  if (p.bias) v += bf2f(p.bias[n]);
+  if (act != TD_ACT_NONE) v = act_rt(act, rbf(v));
+  else {
+    if (p.gate) v = rbf(v) * bf2f(p.gate[n]);
+    if (p.res) v = rbf(v) + bf2f(p.res[(size_t)m * p.ldr + n]);
+  }
+  if (second) p.C2[(size_t)m * p.ldc2 + (n - p.n_split)] = f2bf(v);
+  else p.C[(size_t)m * p.ldc + n] = f2bf(v);
+}
+
+}  // namespace
+
+int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
+  TD_CHECK_ARG(p.M >= 1 && p.M <= 8 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 8, N %% 4 == 0, K %% 8 == 0");
+  TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W) % 16 == 0, "td_gemv: operands must be 16-byte aligned");
+  const dim3 grid(p.N / R), block(THREADS);
+  if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, grid, block, 0, stream, p);
+  else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, grid, block, 0, stream, p);
+  else if (p.M <= 4) hipLaunchKernelGGL(td_gemv_bf16_kernel<4>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(td_gemv_bf16_kernel<8>, grid, block, 0, stream, p);
+  TD_CHECK_LAUNCH();
+  return 0;
+}

@@ -35,6 +35,8 @@ struct TdGemmParams {
 };
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);
+// weight-streaming form for M <= 8 (td_gemm_launch routes to it; csrc/gemv_bf16.hip)
+int td_gemv_launch(const TdGemmParams& p, hipStream_t stream);
 // 0: 256x256 (td_gemm_bf16_nt_kernel<8,4>), 1: 256x64, 2: 32x256, 3: 288x192 (<9,3>)
 int td_gemm_config_id(int M, int N, int K);
 
