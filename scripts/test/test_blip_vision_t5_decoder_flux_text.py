@@ -61,6 +61,7 @@ class ClipFluxDriver:
             raise FileNotFoundError("no FLUX weights: set run.local_weights.flux to a local diffusers directory or run.synthetic: true")
         self.text = providers.load_text_encoders(run, self.pipe, self.device)
         self.pipe.set_progress_bar_config(disable=True)
+        self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"))   # "fp8": BASELINE config 5's e4m3 block GEMMs
 
     # ---- config surface (reference :117-161) ---------------------------------------------------------------
     def resolve_inputs(self):
@@ -105,33 +106,61 @@ class ClipFluxDriver:
         pe, pooled, _ = self.pipe.encode_prompt(prompt=prompt, prompt_2=None, max_sequence_length=max_len)
         return pe, pooled
 
-    def render(self, img_url, prompt, out_path):
+    def condition(self, img_url, prompt):
+        """[aligner(img1), aligner(img2) ..., T5(prompt)] along the token axis + the CLIP pooled vector (reference :221-233)."""
         run = self.cfg.run_cfg
         urls = img_url if type(img_url) == list else [img_url]
+        vis = [self.aligner_tokens(u, prompt) for u in urls]                       # [1,65,4096] each
+        t5, pooled = self.text_tokens(prompt, run["flux_max_sequence_length"])
+        return torch.cat(vis + [t5], dim=1).to(torch.bfloat16), pooled.to(torch.bfloat16)   # visual tokens first, then T5
+
+    def render_group(self, jobs):
+        """jobs: [(img_url, prompt, out_path)] with equal token counts.  One pipeline call; the images advance concurrently
+        on the engine's forked contexts.  Latents are drawn job by job from the global generator, i.e. exactly the draws
+        the reference's one-call-per-image loop makes, so grouping does not change any image."""
+        run = self.cfg.run_cfg
         with torch.no_grad():
-            vis = [self.aligner_tokens(u, prompt) for u in urls]                       # [1,65,4096] each
-            t5, pooled = self.text_tokens(prompt, run["flux_max_sequence_length"])
-            prompt_embeds = torch.cat(vis + [t5], dim=1)                               # visual tokens first, then T5
-            images = self.pipe(prompt_embeds=prompt_embeds.to(torch.bfloat16), pooled_prompt_embeds=pooled.to(torch.bfloat16),
-                               num_images_per_prompt=1, height=run["flux_height"], width=run["flux_width"],
+            conds = [self.condition(u, p) for u, p, _ in jobs]
+            lat = torch.cat([self.pipe.prepare_latents(1, run["flux_height"], run["flux_width"])[0] for _ in jobs])
+            images = self.pipe(prompt_embeds=torch.cat([c[0] for c in conds]), pooled_prompt_embeds=torch.cat([c[1] for c in conds]),
+                               num_images_per_prompt=1, height=run["flux_height"], width=run["flux_width"], latents=lat,
                                num_inference_steps=run["flux_num_inference_steps"], guidance_scale=run["guidance_scale"]).images
-        images[0].save(out_path, format="PNG", compress_level=1)
-        print(f"Image saved to {out_path}")
+        for img, (_, _, out_path) in zip(images, jobs):
+            img.save(out_path, format="PNG", compress_level=1)
+            print(f"Image saved to {out_path}")
+
+    def render(self, img_url, prompt, out_path):
+        self.render_group([(img_url, prompt, out_path)])
 
     def run(self):
-        out_dir = self.cfg.run_cfg["output_dir"]
+        run = self.cfg.run_cfg
+        out_dir = run["output_dir"]
         os.makedirs(out_dir, exist_ok=True)
         urls, names, questions, q_names = self.resolve_inputs()
-        written = []
+        G = max(1, int(run.get("images_in_flight", 3)))      # images rendered per pipeline call (MI355X: fills kernel tails)
+        self.pipe.images_in_flight = G
+        written, pending = [], []
+
+        def flush():
+            if pending:
+                self.render_group(list(pending))
+                written.extend(j[2] for j in pending)
+                pending.clear()
+
         for i, url in enumerate(urls):
             jobs = [(questions[names[i]], None)] if q_names is None else list(zip(questions, q_names))
             for prompt, pname in jobs:
                 path = self.output_path(out_dir, names[i], prompt, pname)
-                if os.path.exists(path):
+                if os.path.exists(path) or any(path == j[2] for j in pending):
                     print(f"Image already exists at {path}")
                     continue
-                self.render(url, prompt, path)
-                written.append(path)
+                n_img = len(url) if type(url) == list else 1
+                if pending and (len(pending[0][0]) if type(pending[0][0]) == list else 1) != n_img:
+                    flush()                                    # a group shares one token count
+                pending.append((url, prompt, path))
+                if len(pending) == G:
+                    flush()
+        flush()
         return written
 
 

@@ -28,3 +28,28 @@ def test_clip_image_text_driver_writes_png(hip, tmp_path):
     im = Image.open(written[0])
     assert im.size == (256, 256) and im.mode == "RGB"
     assert drv.main(argv) == []          # second run: "Image already exists", nothing rendered
+
+
+def test_driver_groups_images_in_flight_without_changing_them(hip, tmp_path):
+    """4 (image, prompt) jobs incl. a two-image composition (BASELINE config 5's driver shape): rendering in groups of 3
+    (engine contexts on separate streams) writes the same PNG bytes as one image at a time, in bf16 and in fp8."""
+    import hashlib
+    from scripts.test import test_blip_vision_t5_decoder_flux_text as drv
+    imgs = []
+    for k, col in enumerate([(120, 80, 40), (10, 200, 90), (250, 250, 0)]):
+        p = tmp_path / f"img{k}.jpg"
+        Image.new("RGB", (64 + 8 * k, 64), col).save(p)
+        imgs.append(str(p))
+    base = ["--cfg-path", os.path.join(HERE, "golden", "thinkdiff_clip_driver_keys.yaml"), "--options",
+            "run.synthetic=true", "run.synthetic_tiny=true", "run.flux_height=128", "run.flux_width=128",
+            "run.flux_num_inference_steps=2", f"run.img_urls=[{imgs[0]},{imgs[1]},{imgs[2]},[{imgs[0]},{imgs[1]}]]",
+            "run.questions=[a red apple]", "run.questions_names=[apple]", "run.prompt_json=", "run.use_image_name_and_prompt_as_output_name=false", "model.ckpt="]
+    digests = {}
+    for prec in ("bf16", "fp8"):
+        for G in (1, 3):
+            out = tmp_path / f"out_{prec}_{G}"
+            written = drv.main(base + [f"run.output_dir={out}", f"run.images_in_flight={G}", f"run.flux_precision={prec}"])
+            assert len(written) == 4 and os.path.basename(written[3]).startswith("img0_img1_apple")
+            digests[prec, G] = [hashlib.sha256(open(w, "rb").read()).hexdigest() for w in written]
+        assert digests[prec, 1] == digests[prec, 3]
+    assert digests["bf16", 1] != digests["fp8", 1]

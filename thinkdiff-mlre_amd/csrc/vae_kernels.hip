@@ -26,14 +26,13 @@ __device__ __forceinline__ u32x4_t pack8v(const float (&f)[8]) {
 // ---- GroupNorm, pass 1: per-block partial sums.  x [P, C] NHWC, G groups of C/G channels --------------
 // partial[block][g][0..1] = (sum, sum of squares) over the block's pixels
 __global__ __launch_bounds__(256) void td_gn_partial_kernel(const bf16_t* x, int P, int C, int G, int pix_per_block, float* partial) {
-  __shared__ float acc[64][2];
-  if (threadIdx.x < 64) { acc[threadIdx.x][0] = 0.f; acc[threadIdx.x][1] = 0.f; }
-  __syncthreads();
+  // per-thread sub-sums, then a fixed-order sum per group: bit-reproducible (shared-memory float atomics are not)
+  __shared__ float buf[256][8][2];
   const int tpp = C / 8;                       // threads per pixel
   const int ppp = 256 / tpp;                   // pixels per pass (C <= 2048)
   const int c0 = (threadIdx.x % tpp) * 8;
   const int p_in = threadIdx.x / tpp;
-  const int cpg = C / G;
+  const int cpg = C / G;                       // 1, 2, 4 or a multiple of 8 (checked by the launcher)
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
@@ -45,16 +44,27 @@ __global__ __launch_bounds__(256) void td_gn_partial_kernel(const bf16_t* x, int
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
     }
+  const int nsub = cpg >= 8 ? 1 : 8 / cpg, per = 8 / nsub;   // sub-groups of this thread's 8 channels
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int g = (c0 + i) / cpg;
-    atomicAdd(&acc[g][0], s[i]);
-    atomicAdd(&acc[g][1], q[i]);
+  for (int u = 0; u < 8; ++u) {
+    float su = 0.f, qu = 0.f;
+    if (u < nsub)
+      for (int i = 0; i < per; ++i) { su += s[u * per + i]; qu += q[u * per + i]; }
+    buf[threadIdx.x][u][0] = su;
+    buf[threadIdx.x][u][1] = qu;
   }
   __syncthreads();
   if (threadIdx.x < G) {
-    partial[((size_t)blockIdx.x * G + threadIdx.x) * 2] = acc[threadIdx.x][0];
-    partial[((size_t)blockIdx.x * G + threadIdx.x) * 2 + 1] = acc[threadIdx.x][1];
+    const int g = threadIdx.x;
+    float su = 0.f, qu = 0.f;
+    const int j0 = g * cpg / 8, nj = cpg >= 8 ? cpg / 8 : 1, sub = cpg >= 8 ? 0 : g % nsub;
+    for (int pp = 0; pp < ppp; ++pp)
+      for (int j = j0; j < j0 + nj; ++j) {
+        su += buf[pp * tpp + j][sub][0];
+        qu += buf[pp * tpp + j][sub][1];
+      }
+    partial[((size_t)blockIdx.x * G + g) * 2] = su;
+    partial[((size_t)blockIdx.x * G + g) * 2 + 1] = qu;
   }
 }
 
@@ -103,6 +113,7 @@ __global__ __launch_bounds__(256) void td_gn_apply_kernel(const bf16_t* x, bf16_
 int td_groupnorm_nhwc_launch(const bf16_t* x, bf16_t* y, int P, int C, int G, float eps, const bf16_t* gamma, const bf16_t* beta,
                              int silu, float* workspace, hipStream_t stream) {
   TD_CHECK_ARG(P > 0 && C % 8 == 0 && C <= 2048 && G > 0 && G <= 64 && C % G == 0, "td_groupnorm: bad shape P=%d C=%d G=%d", P, C, G);
+  TD_CHECK_ARG((C / G) % 8 == 0 || 8 % (C / G) == 0, "td_groupnorm: channels per group (%d) must divide 8 or be a multiple of 8", C / G);
   TD_CHECK_ARG(workspace != nullptr, "td_groupnorm: workspace of td_groupnorm_workspace_floats() floats required");
   const int nblocks = min(1024, (P + 63) / 64);
   const int ppb = (P + nblocks - 1) / nblocks;

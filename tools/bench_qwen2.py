@@ -34,3 +34,15 @@ for i in range(N):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / N * 1e3
 print(f"decode (cache {n0}): {ms:.3f} ms/token -> {2*params/ms/1e6:.0f} GB/s of weights   (128 tokens = {128*ms:.0f} ms)")
+
+# the reference's request shape: ~300-token prompt, 128 sampled tokens (T=0.6, top-p 0.9, ignore_eos), hidden states captured
+from thinkdiff.models.qwen2_vl import SamplingParams
+sp = SamplingParams(temperature=0.6, top_p=0.9, max_tokens=128, min_tokens=128, ignore_eos=True)
+prompt = torch.randint(0, cfg.vocab_size, (300,)).tolist()
+gen = torch.Generator(device="cuda").manual_seed(0)
+e.generate(prompt, sp, generator=gen); torch.cuda.synchronize()
+t0 = time.perf_counter()
+out = e.generate(prompt, sp, generator=gen)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"generate(): 300-token prompt + 128 sampled tokens with hidden states: {dt*1e3:.0f} ms ({out['hidden_states'].shape[0]} states)")
