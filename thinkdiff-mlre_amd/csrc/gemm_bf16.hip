@@ -529,7 +529,7 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
 
 }  // namespace
 
-// Tile choice.  0: 256x256, 1: 256x64, 2: 32x256, 3: 288x192.  Measured on MI355X (in-process A/B,
+// Tile choice.  0: 256x256, 1: 256x64 (also: few-tile problems), 2: 32x256, 3: 288x192.  Measured on MI355X (in-process A/B,
 // tools/bench_ops.py gemmcfg): 256x256 wins whenever the grid spans several rounds of the 256 CUs; the
 // 288x192 tile wins where 256x256 leaves a single ragged round (N = 3072 at M = 4289: 204 tiles, but 240
 // tiles of the smaller shape) and K is long enough to amortise its prologue.
@@ -538,7 +538,10 @@ int td_gemm_config_id(int M, int N, int K) {
   if (M <= 32) return 2;
   const long long t0 = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const long long t3 = (long long)((M + 287) / 288) * ((N + 191) / 192);
-  return (t0 < 230 && t3 <= 256 && t3 > t0 && K >= 6144) ? 3 : 0;
+  if (t0 < 230 && t3 <= 256 && t3 > t0 && K >= 6144 && M > 1024) return 3;
+  // few 256x256 tiles (encoders, towers, short prefills: M of 77-1024 rows, N of a few thousand): a quarter-width tile
+  // puts 4x the workgroups on the chip; measured 25-30 % faster below ~96 tiles, slower above (tools/bench_ops.py gemmsmall)
+  return t0 < 96 ? 1 : 0;
 }
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {

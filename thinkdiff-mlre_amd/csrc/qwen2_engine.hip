@@ -232,7 +232,8 @@ int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embed
       g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = n; g.N = QW + KVW; g.K = D;
       g.C = f->q; g.ldc = QW; g.C2 = kv_new; g.ldc2 = KVW; g.n_split = QW;
       if (QW % 256 == 0) {
-        g.cfg = n <= 32 ? -1 : 0;   // the column split needs 256-wide tiles (small-M and 256x256 tiles both are)
+        // the column split needs a tile width that divides 256: every config but the 288x192 one
+        g.cfg = n <= 32 ? -1 : (td_gemm_config_id(n, QW + KVW, D) == 1 ? 1 : 0);
         TDQ_TRY(td_gemm_launch(g, s));
       } else {
         TdGemmParams a = g; a.C2 = nullptr; a.N = QW;

@@ -89,6 +89,24 @@ def bench_gemmfp8():
         del pool, qpool
 
 
+def bench_gemmsmall():
+    """Mid-M Linears (encoders, towers, short prefills): 256x256 tiles (cfg 0) vs 256x64 tiles (cfg 1) vs 32x256 (cfg 2, M <= 32)."""
+    for M, N, K in [(128, 24576, 4096), (128, 20480, 4096), (128, 4096, 10240), (300, 4608, 3584), (300, 37888, 3584), (300, 3584, 18944),
+                    (257, 6144, 1408), (257, 1408, 6144), (77, 3072, 768), (512, 4096, 4096), (1024, 3840, 1280)]:
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(max(2, int(6e8 // (N * K * 2))))]
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        st = {"i": 0}
+        res = {}
+        for cfg in (0, 1):
+            def f():
+                st["i"] = (st["i"] + 1) % len(pool)
+                _hip.linear_grouped2(x, pool[st["i"]], None, y, None, None, None, None, tile_cfg=cfg)
+            res[cfg] = min(timeit(f, iters=10, warmup=2) for _ in range(3))
+        print(f"M={M} N={N} K={K}: cfg0 {res[0]*1e3:7.1f} us   cfg1 {res[1]*1e3:7.1f} us   weights {N*K*2/1e6:.0f} MB -> {N*K*2/min(res.values())/1e6:.0f} GB/s", flush=True)
+        del pool
+
+
 def bench_gemmcold():
     """Tile/pipeline variants with L3-warm weights (one W re-used) vs cold weights (cycling a 1 GB pool, as in
     the real denoise loop where every layer's weights stream from HBM).  Interleaved rounds, best-of."""
