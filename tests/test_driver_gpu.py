@@ -53,3 +53,21 @@ def test_driver_groups_images_in_flight_without_changing_them(hip, tmp_path):
             digests[prec, G] = [hashlib.sha256(open(w, "rb").read()).hexdigest() for w in written]
         assert digests[prec, 1] == digests[prec, 3]
     assert digests["bf16", 1] != digests["fp8", 1]
+
+
+def test_lvlm_image_instruction_driver_writes_png(hip, tmp_path):
+    """BASELINE config 3 in miniature: image + instruction -> Qwen2-VL ViT + decoder (sampled tokens, hidden states) ->
+    aligner -> FLUX -> VAE -> PNG, through the reference's config surface and output naming."""
+    from scripts.test import test_mllama_t5_decoder_flux as drv
+    img = tmp_path / "dot_image.jpeg"
+    Image.new("RGB", (280, 196), (30, 90, 200)).save(img)
+    out = tmp_path / "out"
+    argv = ["--cfg-path", os.path.join(HERE, "golden", "thinkdiff_lvlm_driver_keys.yaml"), "--options",
+            "run.synthetic=true", "run.synthetic_tiny=true", "run.distributed=false", f"run.img_urls=[{img}]", f"run.output_dir={out}",
+            "run.flux_height=256", "run.flux_width=256", "run.flux_num_inference_steps=2", "model.ckpt=",
+            "model.vllm_config.max_model_len=1024", "model.vllm_config.max_tokens=16", "model.vllm_config.min_tokens=16",
+            "model.text_config={hidden_size: 512, num_hidden_layers: 2, num_attention_heads: 4, num_key_value_heads: 2, intermediate_size: 1024, vocab_size: 152064}"]
+    written = drv.main(argv)
+    assert [os.path.basename(w) for w in written] == ["dot_image_output_embed_flux_0.png"]
+    im = Image.open(written[0])
+    assert im.size == (256, 256) and im.mode == "RGB"

@@ -29,7 +29,7 @@ NUM_SYSTEM_TOKENS = 14                            # reference :1107-1109 ("input
 
 @registry.register_model("mllama-vllm-t5-embed-decoder-5")
 class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
-    PRETRAINED_MODEL_CONFIG_DICT = {"pretrain_mllama_vllm_t5_embed_decoder": "configs/models/mllama_vllm_t5_embed_decoder.yaml"}
+    PRETRAINED_MODEL_CONFIG_DICT = {"pretrain_mllama_vllm_t5_embed_decoder_5": "configs/models/mllama_vllm_t5_embed_decoder_5.yaml"}   # reference :781-783
 
     def __init__(self, text_config: Qwen2VLTextConfig = None, vllm_config: dict = None, hidden_size: int = 4096,
                  mm_projector_type: str = "mlp2x_gelu_t5_norm", device="cuda", tokenizer=None, processor=None,
@@ -51,7 +51,9 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
     def from_config(cls, cfg):
         vc = cfg.get("vllm_config", {})
         vc = vc.to_dict() if hasattr(vc, "to_dict") else dict(vc)
-        model = cls(vllm_config=vc, mm_projector_type=cfg.get("mm_projector_type", "mlp2x_gelu_t5_norm"),
+        tc = cfg.get("text_config", None)       # optional decoder shape override (tests); default = Qwen2-VL-7B
+        tc = Qwen2VLTextConfig(**(tc.to_dict() if hasattr(tc, "to_dict") else dict(tc))) if tc else None
+        model = cls(text_config=tc, vllm_config=vc, mm_projector_type=cfg.get("mm_projector_type", "mlp2x_gelu_t5_norm"),
                     device=cfg.get("device", "cuda"))
         import os
         ckpt = cfg.get("ckpt", "")
@@ -99,6 +101,7 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
         """-> (list[Tensor[n_i, 4096]], list[str]) exactly as the reference (:1019-1118); the second list holds the
         decoded text when a tokenizer is loaded, else the generated token ids as a space-separated string."""
         reqs = self._to_requests(mllama_inputs, need_process)
+        sp = self.mllama_sampling_params    # **generate_kwargs (e.g. the drivers' max_new_tokens=128) are accepted and unused, as in the reference (:1019-1118)
         outs = []
         for i, r in enumerate(reqs):
             if "prompt_token_ids" in r:
@@ -112,7 +115,7 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
                 r = dict(r)
                 ids, r["inputs_embeds"], r["position_ids"] = self._splice_images(ids, mm["image"])
             forced = None if forced_output_ids is None else forced_output_ids[i]
-            outs.append(self.mllama.generate(ids, self.mllama_sampling_params, position_ids=r.get("position_ids"),
+            outs.append(self.mllama.generate(ids, sp, position_ids=r.get("position_ids"),
                                              inputs_embeds=r.get("inputs_embeds"), generator=generator, forced_output_ids=forced))
         inp = [o["prompt_hidden_states"] for o in outs]
         out = [o["hidden_states"] for o in outs]

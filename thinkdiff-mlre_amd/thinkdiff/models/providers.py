@@ -79,3 +79,79 @@ def load_text_encoders(run_cfg, pipe, device):
         pipe.text_encoder_2, pipe.tokenizer_2 = HipT5Encoder.from_random(seed=seed + 12, device=device), HashTokenizer(32128)
         return None
     return SyntheticTextEncoders()
+
+
+# ---- ThinkDiff-LVLM: Qwen2-VL chat template / tokenizer / vision tower ------------------------------------------------
+class SyntheticQwenChat:
+    """Asset-free stand-in for the Qwen2-VL AutoProcessor + tokenizer (synthetic runs): the ChatML layout the real
+    template produces (system / user turns, one <|vision_start|><|image_pad|><|vision_end|> per image, generation prompt),
+    word-hash token ids below the special-token range, and the real HF image processor for the pixels."""
+    IM_START, IM_END, VISION_START, VISION_END, IMAGE_PAD = 151644, 151645, 151652, 151653, 151655
+    SPECIAL = {"<|im_start|>": IM_START, "<|im_end|>": IM_END, "<|vision_start|>": VISION_START,
+               "<|vision_end|>": VISION_END, "<|image_pad|>": IMAGE_PAD}
+
+    def __init__(self, vocab_size: int = 151643, min_pixels: int = 56 * 56, max_pixels: int = 28 * 28 * 1280):
+        self.vocab_size = min(vocab_size, 151643)
+        self._ip_args = dict(min_pixels=min_pixels, max_pixels=max_pixels)
+        self._ip = None
+
+    @property
+    def image_processor(self):
+        if self._ip is None:
+            from transformers import Qwen2VLImageProcessor
+            self._ip = Qwen2VLImageProcessor(**self._ip_args)
+        return self._ip
+
+    def apply_chat_template(self, conversations, tokenize=False, add_generation_prompt=True):
+        out = []
+        for conv in conversations:
+            text = ""
+            for turn in conv:
+                body = turn["content"]
+                if not isinstance(body, str):
+                    body = "".join("<|vision_start|><|image_pad|><|vision_end|>" if part["type"] == "image" else part["text"] for part in body)
+                text += f"<|im_start|>{turn['role']}\n{body}<|im_end|>\n"
+            out.append(text + ("<|im_start|>assistant\n" if add_generation_prompt else ""))
+        return out
+
+    def encode(self, text, add_special_tokens=False):
+        import re
+        import zlib
+        ids = []
+        for piece in re.split(r"(<\|[a-z_]+\|>)", text):
+            if piece in self.SPECIAL:
+                ids.append(self.SPECIAL[piece])
+            else:
+                ids.extend(zlib.crc32(w.encode()) % self.vocab_size for w in piece.split())
+        return ids
+
+    def decode(self, ids, **_kw):
+        return " ".join(f"<{int(i)}>" for i in ids)
+
+
+def load_lvlm_frontend(run_cfg, model, device):
+    """Attach tokenizer / chat processor / image processor / vision tower to the ThinkDiff-LVLM model.
+    `run.local_weights.qwen2_vl`: a local Hugging Face Qwen2-VL directory (weights + processor); `run.synthetic: true`:
+    synthetic weights drawn on the device and the asset-free chat stand-in."""
+    lw = run_cfg.get("local_weights", None) or {}
+    from .vision_towers import HipQwen2VisionTransformer
+    if lw.get("qwen2_vl", None):
+        from transformers import AutoProcessor
+        proc = AutoProcessor.from_pretrained(lw["qwen2_vl"], local_files_only=True)
+        model.mllama_processor, model.mllama_tokenizer, model.image_processor = proc, proc.tokenizer, proc.image_processor
+        model.visual = HipQwen2VisionTransformer.from_pretrained(lw["qwen2_vl"], device=device)
+        model.mllama.load_pretrained(lw["qwen2_vl"])
+        return model
+    if run_cfg.get("synthetic", False):
+        chat = SyntheticQwenChat(vocab_size=model.mllama.config.vocab_size,
+                                 max_pixels=28 * 28 * int(run_cfg.get("synthetic_max_image_tokens", 1280)))
+        model.mllama_processor = model.mllama_tokenizer = chat
+        model.image_processor = chat.image_processor
+        seed = run_cfg.get("seed", 0)
+        if model.visual is None:
+            tiny = run_cfg.get("synthetic_tiny", False)
+            kw = dict(embed_dim=320, depth=2, num_heads=4, mlp_ratio=2) if tiny else {}
+            model.visual = HipQwen2VisionTransformer.from_random(out_hidden=model.mllama.config.hidden_size, seed=seed + 21, device=device, **kw)
+        model.mllama.init_random(seed + 22)
+        return model
+    raise FileNotFoundError("no Qwen2-VL assets: set run.local_weights.qwen2_vl to a local checkpoint directory or run.synthetic: true")

@@ -86,6 +86,30 @@ class Qwen2VLTextEngine:
                 torch.cuda.current_stream().synchronize()
         return missing
 
+    def load_pretrained(self, path: str):
+        """Text-decoder tensors of a LOCAL Hugging Face Qwen2-VL checkpoint directory (*.safetensors; `visual.*` skipped)."""
+        import glob
+        import os
+        from safetensors import safe_open
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        seen = set()
+        for fn in files:
+            with safe_open(fn, framework="pt") as fh:
+                sd = {}
+                for k in fh.keys():
+                    if "visual." in k:
+                        continue
+                    name = k.replace("model.language_model.", "model.")     # newer exports nest the decoder
+                    sd[name] = fh.get_tensor(k)
+                seen.update(sd)
+                self.load_state_dict(sd, strict=False)
+        missing = [k for k in self.param_table() if k not in seen and not (k == "lm_head.weight" and self.config.tie_word_embeddings)]
+        if missing:
+            raise KeyError(f"checkpoint at {path} lacks {len(missing)} decoder tensors, e.g. {missing[:3]}")
+        return self
+
     def init_random(self, seed: int = 0, std: float = 0.02):
         _hip.check(self._L.td_qwen2_init_random(self._h, seed, std, _hip.stream_ptr()))
         return self
