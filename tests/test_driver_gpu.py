@@ -71,3 +71,34 @@ def test_lvlm_image_instruction_driver_writes_png(hip, tmp_path):
     assert [os.path.basename(w) for w in written] == ["dot_image_output_embed_flux_0.png"]
     im = Image.open(written[0])
     assert im.size == (256, 256) and im.mode == "RGB"
+
+
+def test_precompute_job_end_to_end(hip, tmp_path):
+    """BASELINE config 4 in miniature: scripts/generate_embedding_webdataset over two input shards -> output shards with
+    jpg, json (+ generated text / token ids) and the model.norm input / output hidden states as torch.save bytes."""
+    import io
+    import sys
+    import torch
+    sys.path.insert(0, HERE)
+    from test_precompute_cpu import _make_input_shards
+    from scripts import generate_embedding_webdataset as job
+    from thinkdiff.datasets import wds_io
+    idx, n = _make_input_shards(str(tmp_path), n_shards=2, per_shard=3)
+    out = tmp_path / "emb"
+    argv = ["--cfg-path", os.path.join(HERE, "golden", "qwen2_vl_embed_keys.yaml"), "--options", "run.synthetic=true", "run.synthetic_tiny=true",
+            f"datasets.cc_sbu_mllama_vllm_process_wids.build_info.storage={idx}", "datasets.cc_sbu_mllama_vllm_process_wids.batch_size=4",
+            f"run.output_shard_path=[{out},'%06d.tar',7]", "model.vllm_config.max_model_len=1024", "model.vllm_config.max_tokens=12",
+            "model.vllm_config.min_tokens=12", "model.vllm_config.ignore_eos=true",
+            "model.text_config={hidden_size: 512, num_hidden_layers: 2, num_attention_heads: 4, num_key_value_heads: 2, intermediate_size: 1024, vocab_size: 152064}"]
+    res = job.main(argv)
+    stats = res[0] if isinstance(res, list) else res
+    assert stats["samples"] == n and os.path.basename(stats["shards"][0]["url"]) == "000007.tar"
+    seen = {s["__key__"]: s for sh in stats["shards"] for s in wds_io.read_tar_samples(sh["url"])}
+    assert sorted(seen) == [f"sample{k:06d}" for k in range(n)]
+    one = seen["sample000002"]
+    js = one[".json"]
+    assert len(js["output_token_ids"]) == 12 and js["input_prompt"].startswith("<|im_start|>system") and "<|image_pad|>" in js["input_prompt"]
+    oe = torch.load(io.BytesIO(one[".model.norm.output_embed.pth"])) if isinstance(one[".model.norm.output_embed.pth"], bytes) else one[".model.norm.output_embed.pth"]
+    ie = torch.load(io.BytesIO(one[".model.norm.input_embed.pth"])) if isinstance(one[".model.norm.input_embed.pth"], bytes) else one[".model.norm.input_embed.pth"]
+    assert oe.shape == (12, 512) and oe.dtype == torch.bfloat16 and ie.shape == (len(js["input_prompt_token_ids"]), 512)
+    assert js["input_prompt_token_ids"].count(151655) > 1            # the image placeholder was expanded to the merged vision tokens

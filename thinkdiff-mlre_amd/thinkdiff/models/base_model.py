@@ -26,6 +26,9 @@ class BaseModel:
     def eval(self):
         return self
 
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
     def to(self, device=None, dtype=None):
         if device is not None:
             self._device = torch.device(device)

@@ -5,10 +5,10 @@ Mirror of reference thinkdiff/models/mllama_vllm_generate_1.py `MllamaVllmGenera
   {"generated_text": [str], "generated_token": {"input_prompt", "input_prompt_token_ids", "output_text",
    "output_token_ids"}, "generated_embed": {"model.norm": {"output_embed": [Tensor[n_gen,D]], "input_embed":
    [Tensor[n_prompt,D]]}}}.
-The vLLM engine is replaced by `Qwen2VLTextEngine` (HIP).  Tokenisation / chat templating / the vision tower need
-assets or rows that are not built: `request_builder(sample_i) -> {"prompt", "prompt_token_ids",
-optional "inputs_embeds", "position_ids"}` supplies them; the default builder handles text-only requests with
-a caller-provided tokenizer.
+The vLLM engine is replaced by `Qwen2VLTextEngine` (HIP) behind `QwenChatFrontend` (chat template -> token ids -> vision
+tower -> placeholder splice -> M-RoPE positions).  The chat template / tokenizer come from a local Qwen2-VL directory or the
+synthetic stand-in (`providers.load_lvlm_frontend`); `request_builder(samples, i) -> {"prompt", "prompt_token_ids", optional
+"inputs_embeds", "position_ids"}` overrides the whole front end.
 """
 from types import SimpleNamespace
 from typing import Callable, Dict, List, Optional
@@ -18,11 +18,11 @@ import torch
 from .. import _hip
 from ..common.registry import registry
 from .base_model import BaseModel
-from .qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
+from .qwen2_vl import QwenChatFrontend, Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
 
 
 @registry.register_model("mllama-vllm-generate-1")
-class MllamaVllmGenerate_1(BaseModel):
+class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
     PRETRAINED_MODEL_CONFIG_DICT = {"pretrain_mllama_vllm_generate_1": "configs/models/mllama_vllm_generate_1.yaml"}
 
     def __init__(self, text_config: Optional[Qwen2VLTextConfig] = None, vllm_config: Optional[dict] = None,
@@ -35,7 +35,8 @@ class MllamaVllmGenerate_1(BaseModel):
         self.mllama_sampling_params = SamplingParams(
             temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 256),
             min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False))
-        self.mllama_tokenizer = tokenizer
+        self.mllama_tokenizer, self.mllama_processor = tokenizer, None
+        self.visual, self.image_processor, self.image_token_id = None, None, 151655
         self.request_builder = request_builder
         self.eos_token_id = vc.get("eos_token_id", None)
 
@@ -43,7 +44,9 @@ class MllamaVllmGenerate_1(BaseModel):
     def from_config(cls, cfg):
         vc = cfg.get("vllm_config", {})
         vc = vc.to_dict() if hasattr(vc, "to_dict") else dict(vc)
-        return cls(vllm_config=vc, text_input_key=cfg.get("text_input_key", "answers"), device=cfg.get("device", "cuda"))
+        tc = cfg.get("text_config", None)       # optional decoder shape override; default = the Qwen2-VL-7B shape
+        tc = Qwen2VLTextConfig(**(tc.to_dict() if hasattr(tc, "to_dict") else dict(tc))) if tc else None
+        return cls(text_config=tc, vllm_config=vc, text_input_key=cfg.get("text_input_key", "answers"), device=cfg.get("device", "cuda"))
 
     def _request(self, samples: dict, i: int) -> dict:
         if self.request_builder is not None:
@@ -51,6 +54,9 @@ class MllamaVllmGenerate_1(BaseModel):
         texts = samples["answers"] if self.config.text_input_key is None else samples[self.config.text_input_key]
         if self.mllama_tokenizer is None:
             raise _hip.ThinkDiffHipError("MllamaVllmGenerate_1: supply `request_builder` (token ids / vision embeddings) or a tokenizer")
+        if self.mllama_processor is not None:      # reference :543-583: chat template + image, one request per sample
+            images = samples.get("images", None)
+            return self.resolve_request(self.chat_requests([texts[i]], [images[i] if images is not None else None])[0])
         prompt = texts[i]
         return {"prompt": prompt, "prompt_token_ids": self.mllama_tokenizer.encode(prompt, add_special_tokens=False)}
 

@@ -21,14 +21,14 @@ from .. import _hip
 from ..common.registry import registry
 from .base_model import BaseModel
 from .blip_vision_t5_decoder import HipVisionProjector
-from .qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
+from .qwen2_vl import QwenChatFrontend, Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
 
 SYSTEM_PROMPT = "You are a helpful assistant."   # reference :1048
 NUM_SYSTEM_TOKENS = 14                            # reference :1107-1109 ("input_no_system" drops the first 14)
 
 
 @registry.register_model("mllama-vllm-t5-embed-decoder-5")
-class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
+class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(QwenChatFrontend, BaseModel):
     PRETRAINED_MODEL_CONFIG_DICT = {"pretrain_mllama_vllm_t5_embed_decoder_5": "configs/models/mllama_vllm_t5_embed_decoder_5.yaml"}   # reference :781-783
 
     def __init__(self, text_config: Qwen2VLTextConfig = None, vllm_config: dict = None, hidden_size: int = 4096,
@@ -67,33 +67,12 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
 
     def _to_requests(self, mllama_inputs, need_process) -> List[dict]:
         if need_process:
-            texts, images = mllama_inputs["answers"], mllama_inputs.get("images", [None] * len(mllama_inputs["answers"]))
-            if self.mllama_processor is None:
-                raise _hip.ThinkDiffHipError(
-                    "get_embed(need_process=True) needs the Qwen2-VL processor/chat template loaded from a local path; "
-                    "pass need_process=False with {'prompt_token_ids': ...} requests instead")
-            msgs = [[{"role": "system", "content": SYSTEM_PROMPT},
-                     {"role": "user", "content": ([{"type": "image", "image": im}] if im is not None else []) + [{"type": "text", "text": t}]}]
-                    for t, im in zip(texts, images)]
-            prompts = self.mllama_processor.apply_chat_template(msgs, tokenize=False, add_generation_prompt=True)
-            return [{"prompt": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, images)]
+            texts = mllama_inputs["answers"]
+            return self.chat_requests(texts, mllama_inputs.get("images", [None] * len(texts)))
         return mllama_inputs if isinstance(mllama_inputs, list) else [mllama_inputs]
 
     def _splice_images(self, ids, images):
-        """Prompt ids with one placeholder per image -> (expanded ids, inputs_embeds [n, hidden], position_ids [3, n])."""
-        if self.visual is None or self.image_processor is None:
-            raise _hip.ThinkDiffHipError("image request: load the vision tower (visual=HipQwen2VisionTransformer...) and an "
-                                         "image_processor, or supply 'inputs_embeds' and 'position_ids' with the request")
-        images = list(images) if isinstance(images, (list, tuple)) else [images]
-        feats = self.image_processor(images=images, return_tensors="pt")
-        grid = feats["image_grid_thw"].tolist()
-        merged = self.visual(feats["pixel_values"], grid).pooler_output
-        merge = self.visual.merge
-        ids = Qwen2VLTextEngine.expand_image_placeholders(ids, grid, merge, self.image_token_id)
-        emb = self.mllama.embed_tokens(ids)
-        mask = torch.tensor(ids) == self.image_token_id
-        emb[mask.to(emb.device)] = merged
-        return ids, emb, Qwen2VLTextEngine.mrope_position_ids(ids, grid, merge, self.image_token_id)
+        return self.splice_images(ids, images)
 
     @torch.no_grad()
     def get_embed(self, mllama_inputs, embedding_type="both", output_len_factor=1, need_process=True,
@@ -104,16 +83,8 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(BaseModel):
         sp = self.mllama_sampling_params    # **generate_kwargs (e.g. the drivers' max_new_tokens=128) are accepted and unused, as in the reference (:1019-1118)
         outs = []
         for i, r in enumerate(reqs):
-            if "prompt_token_ids" in r:
-                ids = list(r["prompt_token_ids"])
-            elif self.mllama_tokenizer is not None:
-                ids = self.mllama_tokenizer.encode(r["prompt"], add_special_tokens=False)
-            else:
-                raise _hip.ThinkDiffHipError("request has no 'prompt_token_ids' and no tokenizer is loaded")
-            mm = r.get("multi_modal_data") or {}
-            if mm.get("image") is not None and "inputs_embeds" not in r:
-                r = dict(r)
-                ids, r["inputs_embeds"], r["position_ids"] = self._splice_images(ids, mm["image"])
+            r = self.resolve_request(r)
+            ids = list(r["prompt_token_ids"])
             forced = None if forced_output_ids is None else forced_output_ids[i]
             outs.append(self.mllama.generate(ids, sp, position_ids=r.get("position_ids"),
                                              inputs_embeds=r.get("inputs_embeds"), generator=generator, forced_output_ids=forced))

@@ -228,3 +228,53 @@ class Qwen2VLTextEngine:
             sp_ = torch.where(keep, sp_, torch.zeros_like(sp_))
             return int(idx[torch.multinomial(sp_ / sp_.sum(), 1, generator=generator)])
         return int(torch.multinomial(probs, 1, generator=generator))
+
+
+SYSTEM_PROMPT = "You are a helpful assistant."   # reference mllama_vllm_t5_embed_decoder_2.py:1048, mllama_vllm_generate_1.py:551
+
+
+class QwenChatFrontend:
+    """What vLLM's Qwen2-VL input pipeline does around the decoder, shared by the two LVLM model mirrors: ChatML request
+    building, tokenisation, the vision tower, placeholder expansion / embedding splice and M-RoPE positions.
+    Expects on `self`: mllama (Qwen2VLTextEngine), mllama_processor, mllama_tokenizer, image_processor, visual, image_token_id."""
+
+    def chat_requests(self, texts, images) -> List[dict]:
+        """(instruction, [image]) pairs -> [{"prompt", "multi_modal_data": {"image": ...}}] exactly as the reference builds
+        them (system turn + user turn with one image part then the text part, generation prompt appended)."""
+        if self.mllama_processor is None:
+            raise _hip.ThinkDiffHipError(
+                "text requests need the Qwen2-VL processor / chat template loaded from a local path (or the synthetic stand-in); "
+                "pass need_process=False with {'prompt_token_ids': ...} requests instead")
+        msgs = [[{"role": "system", "content": SYSTEM_PROMPT},
+                 {"role": "user", "content": ([{"type": "image", "image": im}] if im is not None else []) + [{"type": "text", "text": t}]}]
+                for t, im in zip(texts, images)]
+        prompts = self.mllama_processor.apply_chat_template(msgs, tokenize=False, add_generation_prompt=True)
+        return [{"prompt": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, images)]
+
+    def splice_images(self, ids, images):
+        """Prompt ids with one placeholder per image -> (expanded ids, inputs_embeds [n, hidden], position_ids [3, n])."""
+        if self.visual is None or self.image_processor is None:
+            raise _hip.ThinkDiffHipError("image request: load the vision tower (visual=HipQwen2VisionTransformer...) and an "
+                                         "image_processor, or supply 'inputs_embeds' and 'position_ids' with the request")
+        images = list(images) if isinstance(images, (list, tuple)) else [images]
+        feats = self.image_processor(images=images, return_tensors="pt")
+        grid = feats["image_grid_thw"].tolist()
+        merged = self.visual(feats["pixel_values"], grid).pooler_output
+        merge = self.visual.merge
+        ids = Qwen2VLTextEngine.expand_image_placeholders(ids, grid, merge, self.image_token_id)
+        emb = self.mllama.embed_tokens(ids)
+        mask = torch.tensor(ids) == self.image_token_id
+        emb[mask.to(emb.device)] = merged
+        return ids, emb, Qwen2VLTextEngine.mrope_position_ids(ids, grid, merge, self.image_token_id)
+
+    def resolve_request(self, r: dict) -> dict:
+        """Fill prompt_token_ids (tokenizer) and, for image requests, inputs_embeds + position_ids."""
+        r = dict(r)
+        if "prompt_token_ids" not in r:
+            if self.mllama_tokenizer is None:
+                raise _hip.ThinkDiffHipError("request has no 'prompt_token_ids' and no tokenizer is loaded")
+            r["prompt_token_ids"] = self.mllama_tokenizer.encode(r["prompt"], add_special_tokens=False)
+        mm = r.get("multi_modal_data") or {}
+        if mm.get("image") is not None and "inputs_embeds" not in r:
+            r["prompt_token_ids"], r["inputs_embeds"], r["position_ids"] = self.splice_images(list(r["prompt_token_ids"]), mm["image"])
+        return r

@@ -24,6 +24,19 @@ def flatten_dict(d, parent_key="", sep="."):
 
 @registry.register_task("image_text_process_data")
 class ImageTextProcessDataTask(BaseTask):
+    def build_datasets(self, cfg):
+        """`datasets.cc_sbu_mllama_vllm_process_wids.build_info.storage` = the wids shard index (reference builder
+        thinkdiff/datasets/builders/image_text_pair_builder.py + datasets/datasets/cc_sbu_dataset_mllama_vllm_process_wids.py:36-63);
+        the shard list is split by rank here (one process per GPU, no data-path collective)."""
+        from ..common.dist_utils import get_rank, get_world_size
+        from ..datasets.cc_sbu_process import CCSBUMllamaVllmProcessDatasetWids
+        out = {}
+        for name in cfg.datasets_cfg:
+            dc = cfg.datasets_cfg[name]
+            if name == "cc_sbu_mllama_vllm_process_wids":
+                out[name] = CCSBUMllamaVllmProcessDatasetWids(dc["build_info"]["storage"], rank=get_rank(), world=get_world_size())
+        return out
+
     def _train_inner_loop(self, epoch, iters_per_epoch, model, data_loader, optimizer=None, lr_scheduler=None, scaler=None,
                           start_iters=None, log_freq=50, cuda_enabled=False, accum_grad_iters=1, amp_dtype=torch.bfloat16,
                           use_clip_grad_norm=False, max_grad_norm=1.0, output_shard_path=None, maxsize=(10 ** 8) * 5):
