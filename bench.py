@@ -129,6 +129,9 @@ def main():
     if world > 1 or os.environ.get("TD_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box rehearse the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
