@@ -294,6 +294,21 @@ int td_qwen2_init_random(td_qwen2* f, uint64_t seed, float std, void* stream);
  * NULL); logits_last bf16[vocab] of the last token (may be NULL).  pos0 = 0 is a prefill; pos0 > 0 continues. */
 int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
                      int pos0, void* hidden_out, void* logits_last, void* stream);
+/* td_qwen2_forward on sequence `slot` of a handle partitioned by td_qwen2_set_slots (td_qwen2_forward = slot 0). */
+int td_qwen2_forward_slot(td_qwen2* f, int slot, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
+                          int pos0, void* hidden_out, void* logits_last, void* stream);
+/* Batched KV-cached decode (the precompute job, mllama_vllm_generate_1.py:585: vLLM decodes its whole request batch together):
+ * the cache of max_tokens rows per layer is split into n_slots sequences of max_tokens / n_slots rows. */
+int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, td_qwen2** out);   /* n_slots sequences of slot_len tokens */
+int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache rows of an existing handle */
+int td_qwen2_slot_capacity(const td_qwen2* f);
+/* copy the first `len` cache rows of sequence src to sequence dst (compaction when a sequence finishes) */
+int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream);
+/* One new token for each of the sequences in slots 0..B-1 (B <= 16) in one pass over the weights: token_ids int32[B],
+ * position_ids int32[3,B] (device); cache_pos[b] = tokens already cached for sequence b (HOST ints); hidden_out bf16[B,hidden],
+ * logits bf16[B,vocab] (either may be NULL). */
+int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
+                          void* hidden_out, void* logits, void* stream);
 /* out bf16[n,hidden] = embed_tokens[token_ids] (device int32[n]): the host splices vision tokens into this to form inputs_embeds. */
 int td_qwen2_embed_tokens(td_qwen2* f, const int* token_ids, void* out, int n, void* stream);
 

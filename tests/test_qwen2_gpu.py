@@ -145,3 +145,39 @@ def test_precompute_job_end_to_end(hip, tmp_path):
     ref, _ = Q.text_model_hidden(sd, cfg, Q.text_position_ids(9), token_ids=toks)
     got = torch.cat([rec[".model.norm.input_embed.pth"], rec[".model.norm.output_embed.pth"]])
     assert _rel(got, ref) < 2e-2
+
+
+def test_batched_decode_equals_one_sequence_at_a_time(hip):
+    """generate_batch (prefill per slot, then every step advances all live sequences in one pass over the weights, with
+    slot compaction as sequences finish) against generate() run per request: same hidden states, teacher-forced ids of
+    different lengths, prompts of different lengths, one request with non-trivial M-RoPE streams."""
+    from thinkdiff.models.qwen2_vl import SamplingParams
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=11)
+    e = _engine(cfg, sd, max_len=2048)
+    g = torch.Generator().manual_seed(4)
+    lens, gens = [37, 5, 120, 64, 9], [12, 3, 7, 12, 1]
+    reqs, forced = [], []
+    for n, k in zip(lens, gens):
+        ids = torch.randint(0, cfg.vocab, (n,), generator=g).tolist()
+        reqs.append({"prompt_token_ids": ids})
+        forced.append(torch.randint(0, cfg.vocab, (k,), generator=g).tolist())
+    reqs[2]["position_ids"] = torch.stack([torch.arange(120), torch.arange(120) // 3 + 2, (torch.arange(120) * 2) % 11]).to(torch.int32)
+    sp = SamplingParams(max_tokens=12, min_tokens=12, ignore_eos=True)
+    single = [e.generate(r["prompt_token_ids"], sp, position_ids=r.get("position_ids"), forced_output_ids=f) for r, f in zip(reqs, forced)]
+    single = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in single]
+    e.set_slots(8)
+    assert e.slot_len == 256
+    batch = e.generate_batch(reqs, sp, forced_output_ids=forced)
+    torch.cuda.synchronize()
+    for a, b, k in zip(single, batch, gens):
+        assert b["token_ids"] == a["token_ids"] and b["hidden_states"].shape == (k, cfg.hidden)
+        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 1e-6
+        assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
+    # sampled continuation: every sequence yields max_tokens tokens and hidden states, greedy = argmax of its own logits
+    sp0 = SamplingParams(temperature=0.0, max_tokens=6, min_tokens=6, ignore_eos=True)
+    gb = e.generate_batch(reqs[:3], sp0)
+    e.set_slots(1)
+    for r, o in zip(reqs[:3], gb):
+        ref = e.generate(r["prompt_token_ids"], sp0, position_ids=r.get("position_ids"))
+        assert o["token_ids"] == ref["token_ids"] and _rel(o["hidden_states"], ref["hidden_states"]) < 5e-3

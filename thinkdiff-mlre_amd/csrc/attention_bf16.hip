@@ -312,14 +312,20 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   bf16_t* Ob = p.O + (size_t)batch * p.o_bstride;
 
   const unsigned q_bytes = (unsigned)(((long long)(p.Sq - 1) * p.ldq + p.Hq * D) * 2);
-  const unsigned kv_bytes = (unsigned)(((long long)(p.Skv - 1) * p.ldkv + p.Hkv * D) * 2);
+  // batched KV-cached decode: sequence `batch` has its own cache length (causal instantiation only, so the joint-attention
+  // instruction stream of FLUX is untouched); keys visible to query row q: key <= q + (Skv - Sq)
+  int Skv = p.Skv, c_off = p.causal_offset;
+  if constexpr (CAUSAL) {
+    if (p.kv_lens) { Skv = p.kv_lens[batch]; c_off = Skv - p.Sq; }
+  }
+  const unsigned kv_bytes = (unsigned)(((long long)(Skv - 1) * p.ldkv + p.Hkv * D) * 2);
   __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, q_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, kv_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, kv_bytes, 0x00020000);
 
-  int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
+  int nt = (Skv + KV_TILE - 1) / KV_TILE;
   if (CAUSAL) {
-    const int last_q = min(p.Sq, (qblk + 1) * NWAVES * Q_WAVE) - 1 + p.causal_offset;
+    const int last_q = min(p.Sq, (qblk + 1) * NWAVES * Q_WAVE) - 1 + c_off;
     nt = min(nt, last_q / KV_TILE + 1);
   }
 
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   float m_run = -1e30f;
   float l_run = 0.f;
   const float c = p.scale * 1.4426950408889634f;
-  const int q_pos = q0 + l31 + p.causal_offset;
+  const int q_pos = q0 + l31 + c_off;
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < nt; ++t) {
@@ -432,14 +438,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
           }
         }
     }
-    const bool need_mask = (key0 + KV_TILE > p.Skv) || (CAUSAL && key0 + KV_TILE - 1 > q0 + p.causal_offset);
+    const bool need_mask = (key0 + KV_TILE > Skv) || (CAUSAL && key0 + KV_TILE - 1 > q0 + c_off);
     if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-          if ((key >= p.Skv) || (CAUSAL && key > q_pos)) st[kb][r] = -INFINITY;
+          if ((key >= Skv) || (CAUSAL && key > q_pos)) st[kb][r] = -INFINITY;
         }
     }
 
@@ -556,7 +562,8 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
   const int lds = 4 * TILE_BYTES;
   if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
-  if (p.variant == 1 && !p.bias) {
+  if (p.kv_lens) TD_CHECK_ARG(p.causal && !p.bias, "td_attention: per-sequence kv lengths exist for the causal kernel only");
+  if (p.variant == 1 && !p.bias && !p.kv_lens) {
     if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW, false>), grid, dim3(NW * 64), lds, stream, q);
     else hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW, false>), grid, dim3(NW * 64), lds, stream, q);
   } else if (p.bias) {   // separate instantiation: the score-bias loads must not touch the hot no-bias instruction stream

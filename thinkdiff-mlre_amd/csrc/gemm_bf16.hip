@@ -566,8 +566,8 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_ARG(p.conv_up == 0 || (p.conv_H % 2 == 0 && p.conv_W % 2 == 0), "td_gemm(conv): upsampled output dims must be even");
     return p.N <= 64 ? launch_cfg<8, 1, 2, true>(p, stream) : launch_cfg<8, 4, 2, true>(p, stream);
   }
-  // M <= 8 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode, embedders, lm_head)
-  if (p.M <= 8 && p.g_M == 0 && !p.fp8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0) return td_gemv_launch(p, stream);
+  // M <= 16 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode of up to 16 sequences, embedders, lm_head)
+  if (p.M <= 16 && p.g_M == 0 && !p.fp8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0) return td_gemv_launch(p, stream);
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
   if (p.fp8) {
     TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,

@@ -1,4 +1,4 @@
-// Skinny-M Linear for gfx950: y[M<=8, N] = epilogue(x[M,K] . W[N,K]^T), the weight-streaming case of the hot path --
+// Skinny-M Linear for gfx950: y[M<=16, N] = epilogue(x[M,K] . W[N,K]^T), the weight-streaming case of the hot path --
 // KV-cached Qwen2-VL decode (one token against 7.6 B parameters: SURVEY.md 8a row A7, HBM roofline), the pooled / timestep
 // embedders of FLUX, lm_head.  The MFMA tile kernel launches N/256 workgroups here (14 for down_proj) and leaves the
 // chip idle; this kernel is a plain HBM stream:
@@ -115,13 +115,14 @@ __global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParam
 }  // namespace
 
 int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
-  TD_CHECK_ARG(p.M >= 1 && p.M <= 8 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 8, N %% 4 == 0, K %% 8 == 0");
+  TD_CHECK_ARG(p.M >= 1 && p.M <= 16 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 16, N %% 4 == 0, K %% 8 == 0");
   TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W) % 16 == 0, "td_gemv: operands must be 16-byte aligned");
   const dim3 grid(p.N / R), block(THREADS);
   if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, grid, block, 0, stream, p);
   else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, grid, block, 0, stream, p);
   else if (p.M <= 4) hipLaunchKernelGGL(td_gemv_bf16_kernel<4>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(td_gemv_bf16_kernel<8>, grid, block, 0, stream, p);
+  else if (p.M <= 8) hipLaunchKernelGGL(td_gemv_bf16_kernel<8>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(td_gemv_bf16_kernel<16>, grid, block, 0, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }

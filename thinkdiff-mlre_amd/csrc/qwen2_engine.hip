@@ -48,6 +48,10 @@ struct td_qwen2 {
   char* ws = nullptr;
   bf16_t *h, *xn, *q, *attn, *gu, *act;
   float *cosT, *sinT;
+  // batched decode: the cache rows of every layer are split into n_slots sequences of slot_len rows
+  int n_slots = 1, slot_len = 0, ws_rows = 0;
+  bf16_t* kvtmp = nullptr;   // [TD_QWEN2_MAX_BATCH, 2 Hkv 128] k|v rows of a decode step before they are scattered
+  int* ibuf = nullptr;       // device ints: kv lengths, scatter offsets
 };
 
 namespace {
@@ -55,6 +59,19 @@ namespace {
 void q_add(td_qwen2* f, const std::string& name, bf16_t* p, int64_t n) {
   f->index[name] = (int)f->slots.size();
   f->slots.push_back({name, p, n});
+}
+
+constexpr int MAX_BATCH = 16;   // td_gemv_bf16_kernel streams the weights once for up to 16 rows
+
+struct IntPack { int v[2 * MAX_BATCH]; };
+__global__ void td_set_ints_kernel(int* dst, IntPack vals, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+// dst_base[off[b] + c] = src[b, c]: the k|v rows of a decode step go to their sequences' cache rows
+__global__ void td_scatter_rows_kernel(const bf16_t* src, bf16_t* dst_base, const int* off, int W) {
+  const int b = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c < W) *(u32x4_t*)(dst_base + (size_t)off[b] + c) = *(const u32x4_t*)(src + (size_t)b * W + c);
 }
 
 #define TDQ_TRY(expr)         \
@@ -67,8 +84,10 @@ void q_add(td_qwen2* f, const std::string& name, bf16_t* p, int64_t n) {
 
 extern "C" {
 
-int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) {
-  TD_CHECK_ARG(cfg && out && max_tokens > 0, "td_qwen2_create: bad arguments");
+// KV cache of n_slots sequences x slot_len rows per layer; activation workspace for slot_len rows (the longest prefill)
+int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, td_qwen2** out) {
+  TD_CHECK_ARG(cfg && out && slot_len > 0 && n_slots > 0 && (long long)slot_len * n_slots < (1ll << 30), "td_qwen2_create: bad arguments");
+  const int max_tokens = slot_len * n_slots;
   TD_CHECK_ARG(cfg->head_dim == 128, "td_qwen2_create: head_dim must be 128");
   TD_CHECK_ARG(cfg->hidden % 512 == 0 && cfg->intermediate % 64 == 0, "td_qwen2_create: hidden %% 512 and intermediate %% 64 must be 0");
   TD_CHECK_ARG(cfg->num_heads % cfg->num_kv_heads == 0, "td_qwen2_create: heads must be a multiple of kv heads");
@@ -79,6 +98,9 @@ int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) {
   const int Hq = f->Hq = cfg->num_heads, Hkv = f->Hkv = cfg->num_kv_heads;
   const int NQKV = (Hq + 2 * Hkv) * 128;
   f->max_tokens = max_tokens;
+  f->slot_len = slot_len;
+  f->n_slots = n_slots;
+  f->ws_rows = slot_len;
   f->layers.resize(cfg->num_layers);
 
   int64_t off = 0;
@@ -125,12 +147,13 @@ int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) {
     q_add(f, p + "post_attention_layernorm.weight", l.ln2_w, D);
   }
 
-  const int64_t n = max_tokens;
+  const int64_t n = slot_len;
   struct Req { void** p; int64_t bytes; };
   std::vector<Req> reqs = {
       {(void**)&f->h, n * D * 2}, {(void**)&f->xn, n * D * 2}, {(void**)&f->q, n * Hq * 128 * 2},
       {(void**)&f->attn, n * Hq * 128 * 2}, {(void**)&f->gu, n * 2 * I * 2}, {(void**)&f->act, n * I * 2},
       {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
+      {(void**)&f->kvtmp, (int64_t)MAX_BATCH * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4},
   };
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
@@ -201,10 +224,11 @@ int td_qwen2_embed_tokens(td_qwen2* f, const int* token_ids, void* out, int n, v
 //   hidden_out : device bf16 [n, hidden] = model.norm(h)  -- the embedding the reference captures
 //                ("embedding_layer_name: model.norm"); may be NULL
 //   logits_last: device bf16 [vocab] for the LAST of the n tokens (lm_head), or NULL
-int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
-                     int pos0, void* hidden_out, void* logits_last, void* stream) {
+int td_qwen2_forward_slot(td_qwen2* f, int slot, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
+                          int pos0, void* hidden_out, void* logits_last, void* stream) {
   TD_CHECK_ARG(f && position_ids && (token_ids || inputs_embeds), "td_qwen2_forward: null argument");
-  TD_CHECK_ARG(n > 0 && pos0 >= 0 && pos0 + n <= f->max_tokens, "td_qwen2_forward: positions [%d, %d) exceed the cache capacity %d", pos0, pos0 + n, f->max_tokens);
+  TD_CHECK_ARG(slot >= 0 && slot < f->n_slots, "td_qwen2_forward: slot %d outside the %d configured sequences", slot, f->n_slots);
+  TD_CHECK_ARG(n > 0 && pos0 >= 0 && pos0 + n <= f->slot_len, "td_qwen2_forward: positions [%d, %d) exceed the cache capacity %d", pos0, pos0 + n, f->slot_len);
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
@@ -224,7 +248,8 @@ int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embed
 
   for (int i = 0; i < f->cfg.num_layers; ++i) {
     const QLayer& l = f->layers[i];
-    bf16_t* kv_new = l.kv + (size_t)pos0 * KVW;
+    bf16_t* kv_seq = l.kv + (size_t)slot * f->slot_len * KVW;   // this sequence's cache rows
+    bf16_t* kv_new = kv_seq + (size_t)pos0 * KVW;
     np.w = l.ln1_w;
     TDQ_TRY(td_norm_rows_launch(np, s));
     {  // fused q | k | v projection: q -> scratch, k | v -> this layer's cache rows
@@ -245,7 +270,7 @@ int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embed
     rq.qkv = f->q; TDQ_TRY(td_qk_norm_rope_launch(rq, s));
     rk.qkv = kv_new; TDQ_TRY(td_qk_norm_rope_launch(rk, s));
     TdAttnParams ap;
-    ap.Q = f->q; ap.ldq = QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW; ap.O = f->attn; ap.ldo = QW;
+    ap.Q = f->q; ap.ldq = QW; ap.K = kv_seq; ap.V = kv_seq + Hkv * 128; ap.ldkv = KVW; ap.O = f->attn; ap.ldo = QW;
     ap.batch = 1; ap.Sq = n; ap.Skv = pos0 + n; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f;
     ap.causal = 1; ap.causal_offset = pos0;
     TDQ_TRY(td_attn_launch(ap, s));
@@ -276,6 +301,112 @@ int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embed
     g.M = 1; g.N = f->cfg.vocab; g.K = D;
     TDQ_TRY(td_gemm_launch(g, s));
   }
+  return TD_OK;
+}
+
+// ---- batched KV-cached decode (the precompute job: many short sequences against one pass over the weights) --------------
+int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embeds, const int* position_ids, int n,
+                     int pos0, void* hidden_out, void* logits_last, void* stream) {
+  return td_qwen2_forward_slot(f, 0, token_ids, inputs_embeds, position_ids, n, pos0, hidden_out, logits_last, stream);
+}
+
+int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) { return td_qwen2_create_slots(cfg, max_tokens, 1, out); }
+
+// re-partition the cache rows; a sequence cannot be longer than the activation workspace the handle was created with
+int td_qwen2_set_slots(td_qwen2* f, int n_slots) {
+  TD_CHECK_ARG(f && n_slots >= 1 && n_slots <= f->max_tokens, "td_qwen2_set_slots: bad slot count %d", n_slots);
+  f->n_slots = n_slots;
+  f->slot_len = f->max_tokens / n_slots < f->ws_rows ? f->max_tokens / n_slots : f->ws_rows;
+  return TD_OK;
+}
+
+int td_qwen2_slot_capacity(const td_qwen2* f) { return f ? f->slot_len : 0; }
+
+int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream) {
+  TD_CHECK_ARG(f && src >= 0 && src < f->n_slots && dst >= 0 && dst < f->n_slots && len >= 0 && len <= f->slot_len, "td_qwen2_move_slot: bad arguments");
+  if (src == dst || len == 0) return TD_OK;
+  const size_t KVW = (size_t)2 * f->Hkv * 128;
+  for (const QLayer& l : f->layers)
+    TD_CHECK_HIP(hipMemcpyAsync(l.kv + (size_t)dst * f->slot_len * KVW, l.kv + (size_t)src * f->slot_len * KVW, (size_t)len * KVW * 2,
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TD_OK;
+}
+
+// One new token for each of the sequences in slots 0 .. B-1 (B <= 16): token_ids int32[B], position_ids int32[3,B] (device),
+// cache_pos[b] = tokens already in slot b (HOST ints).  hidden_out bf16[B,hidden], logits bf16[B,vocab] (either may be NULL).
+int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
+                          void* hidden_out, void* logits, void* stream) {
+  TD_CHECK_ARG(f && token_ids && position_ids && cache_pos, "td_qwen2_decode_batch: null argument");
+  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots)", B, MAX_BATCH, f->n_slots);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
+  const int QW = Hq * 128, KVW = 2 * Hkv * 128;
+  IntPack ip;
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) {
+    TD_CHECK_ARG(cache_pos[b] >= 0 && cache_pos[b] < f->slot_len, "td_qwen2_decode_batch: sequence %d is full (%d of %d)", b, cache_pos[b], f->slot_len);
+    ip.v[b] = cache_pos[b] + 1;                                         // keys visible to the new token
+    ip.v[MAX_BATCH + b] = (b * f->slot_len + cache_pos[b]) * KVW;       // its cache row (elements)
+    max_len = cache_pos[b] + 1 > max_len ? cache_pos[b] + 1 : max_len;
+  }
+  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(64), 0, s, f->ibuf, ip, 2 * MAX_BATCH);
+  const int* kv_lens = f->ibuf;
+  const int* row_off = f->ibuf + MAX_BATCH;
+
+  TDQ_TRY(td_embed_gather_launch(token_ids, f->embed_w, f->h, B, D, f->cfg.vocab, s));
+  TDQ_TRY(td_mrope_table_launch(position_ids, B, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
+  TdNormParams np;
+  np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = B; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
+  TdQkRopeParams rq;
+  rq.qkv = f->q; rq.ld = QW; rq.rows = B; rq.Hq = Hq; rq.Hk = 0; rq.q_col = 0; rq.k_col = 0;
+  rq.cos = f->cosT; rq.sin = f->sinT; rq.rotate_half = 2;
+  TdQkRopeParams rk = rq;
+  rk.qkv = f->kvtmp; rk.ld = KVW; rk.Hq = Hkv;
+  for (int i = 0; i < f->cfg.num_layers; ++i) {
+    const QLayer& l = f->layers[i];
+    np.w = l.ln1_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = B; g.N = QW + KVW; g.K = D;
+      g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
+      TDQ_TRY(td_gemm_launch(g, s));
+    }
+    TDQ_TRY(td_qk_norm_rope_launch(rq, s));
+    TDQ_TRY(td_qk_norm_rope_launch(rk, s));
+    hipLaunchKernelGGL(td_scatter_rows_kernel, dim3((KVW / 8 + 255) / 256, B), dim3(256), 0, s, f->kvtmp, l.kv, row_off, KVW);
+    TdAttnParams ap;
+    ap.Q = f->q; ap.ldq = QW; ap.q_bstride = QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW;
+    ap.kv_bstride = (long long)f->slot_len * KVW; ap.O = f->attn; ap.ldo = QW; ap.o_bstride = QW;
+    ap.batch = B; ap.Sq = 1; ap.Skv = max_len; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f;
+    ap.causal = 1; ap.causal_offset = max_len - 1; ap.kv_lens = kv_lens;
+    TDQ_TRY(td_attn_launch(ap, s));
+    {
+      TdGemmParams g;
+      g.A = f->attn; g.lda = QW; g.W = l.o_w; g.C = f->h; g.ldc = D; g.res = f->h; g.ldr = D; g.M = B; g.N = D; g.K = QW;
+      TDQ_TRY(td_gemm_launch(g, s));
+    }
+    np.w = l.ln2_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = B; g.N = 2 * I; g.K = D;
+      TDQ_TRY(td_gemm_launch(g, s));
+      TDQ_TRY(td_silu_mul_launch(f->gu, f->act, B, I, s));
+      TdGemmParams d;
+      d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = B; d.N = D; d.K = I;
+      TDQ_TRY(td_gemm_launch(d, s));
+    }
+  }
+  np.w = f->norm_w; np.y = f->xn;
+  TDQ_TRY(td_norm_rows_launch(np, s));
+  if (hidden_out) TD_CHECK_HIP(hipMemcpyAsync(hidden_out, f->xn, (size_t)B * D * 2, hipMemcpyDeviceToDevice, s));
+  if (logits) {
+    TdGemmParams g;
+    g.A = f->xn; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
+    TDQ_TRY(td_gemm_launch(g, s));
+  }
+  TD_CHECK_LAUNCH();
   return TD_OK;
 }
 

@@ -57,6 +57,8 @@ struct TdAttnParams {
   int variant = 0;                    // 0: shipped (lean stream), 1: first lockstep kernel (A/B only)
   // optional additive score bias (T5 relative position bias): fp32 [Hq, Sq, Skv]; scores = q.k*scale + bias
   const float* bias = nullptr;
+  // optional per-batch cache length (device int[batch], causal kernel): sequence b attends keys [0, kv_lens[b]); Skv = the largest
+  const int* kv_lens = nullptr;
 };
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);

@@ -96,6 +96,12 @@ def _declare(L):
         "td_qwen2_init_random": [vp, ctypes.c_uint64, f32, vp],
         "td_qwen2_forward": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
         "td_qwen2_embed_tokens": [vp, vp, vp, i32, vp],
+        "td_qwen2_forward_slot": [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp],
+        "td_qwen2_set_slots": [vp, i32],
+        "td_qwen2_create_slots": [vp, i32, i32, vp],
+        "td_qwen2_slot_capacity": [vp],
+        "td_qwen2_move_slot": [vp, i32, i32, i32, vp],
+        "td_qwen2_decode_batch": [vp, i32, vp, vp, vp, vp, vp, vp],
         "td_embed_gather_bf16": [vp, vp, vp, i32, i32, i32, vp],
         "td_silu_mul_bf16": [vp, vp, i32, i32, vp],
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],

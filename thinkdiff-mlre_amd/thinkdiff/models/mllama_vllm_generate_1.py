@@ -31,7 +31,9 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         vc = dict(vllm_config or {})
         self.config = SimpleNamespace(vllm_config=vc, text_input_key=text_input_key)
         self._device = torch.device(device)
-        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device)
+        # vLLM decodes `max_num_seqs` requests together; here up to 16 sequences share each pass over the weights
+        self.decode_batch = max(1, min(Qwen2VLTextEngine.MAX_BATCH, int(vc.get("max_num_seqs", Qwen2VLTextEngine.MAX_BATCH))))
+        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch)
         self.mllama_sampling_params = SamplingParams(
             temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 256),
             min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False))
@@ -66,18 +68,18 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         layer = self.config.vllm_config.get("embedding_layer_name", "model.norm")
         tok = {"input_prompt": [], "input_prompt_token_ids": [], "output_text": [], "output_token_ids": []}
         out_embed, in_embed, texts = [], [], []
-        for i in range(n):
-            r = self._request(mllama_inputs, i)
-            o = self.mllama.generate(r["prompt_token_ids"], self.mllama_sampling_params, position_ids=r.get("position_ids"),
-                                     inputs_embeds=r.get("inputs_embeds"), eos_token_id=self.eos_token_id, generator=generator)
-            text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
-            tok["input_prompt"].append(r.get("prompt", ""))
-            tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
-            tok["output_text"].append(text)
-            tok["output_token_ids"].append(tuple(o["token_ids"]))
-            texts.append(text)
-            out_embed.append(o["hidden_states"])
-            in_embed.append(o["prompt_hidden_states"])
+        for c0 in range(0, n, self.decode_batch):
+            reqs = [self._request(mllama_inputs, i) for i in range(c0, min(c0 + self.decode_batch, n))]
+            outs = self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator)
+            for r, o in zip(reqs, outs):
+                text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
+                tok["input_prompt"].append(r.get("prompt", ""))
+                tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
+                tok["output_text"].append(text)
+                tok["output_token_ids"].append(tuple(o["token_ids"]))
+                texts.append(text)
+                out_embed.append(o["hidden_states"])
+                in_embed.append(o["prompt_hidden_states"])
         return {"generated_text": texts, "generated_token": tok,
                 "generated_embed": {layer: {"output_embed": out_embed, "input_embed": in_embed}}}
 

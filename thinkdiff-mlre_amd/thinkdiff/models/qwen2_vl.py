@@ -45,7 +45,7 @@ class SamplingParams:
 class Qwen2VLTextEngine:
     dtype = torch.bfloat16
 
-    def __init__(self, config: Optional[Qwen2VLTextConfig] = None, max_model_len: int = 8192, device="cuda", **kw):
+    def __init__(self, config: Optional[Qwen2VLTextConfig] = None, max_model_len: int = 8192, device="cuda", n_slots: int = 1, **kw):
         self.config = config or Qwen2VLTextConfig(**kw)
         c = self.config
         self.device = torch.device(device)
@@ -57,8 +57,10 @@ class Qwen2VLTextEngine:
                                 (ctypes.c_int * 3)(*c.mrope_section), c.rms_norm_eps, c.rope_theta)
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _hip.check(self._L.td_qwen2_create(ctypes.byref(cc), max_model_len, ctypes.byref(h)))
+            # n_slots sequences of max_model_len tokens each (batched decode); n_slots = 1 is the single-request engine
+            _hip.check(self._L.td_qwen2_create_slots(ctypes.byref(cc), max_model_len, int(n_slots), ctypes.byref(h)))
         self._h = h
+        self.n_slots, self.slot_len = int(n_slots), max_model_len
         self.max_model_len = max_model_len
 
     def __del__(self):
@@ -115,7 +117,13 @@ class Qwen2VLTextEngine:
         return self
 
     # ---- one decoder pass over n new tokens ---------------------------------------------------------------
-    def forward(self, position_ids, token_ids=None, inputs_embeds=None, pos0: int = 0, want_hidden=True, want_logits=False):
+    def set_slots(self, n_slots: int):
+        """Split the KV cache into `n_slots` sequences (each max_model_len // n_slots tokens) for batched decode."""
+        _hip.check(self._L.td_qwen2_set_slots(self._h, int(n_slots)))
+        self.n_slots, self.slot_len = int(n_slots), int(self._L.td_qwen2_slot_capacity(self._h))
+        return self
+
+    def forward(self, position_ids, token_ids=None, inputs_embeds=None, pos0: int = 0, want_hidden=True, want_logits=False, slot: int = 0):
         """position_ids int32 [3,n]; token_ids int32 [n] or inputs_embeds bf16 [n,hidden].  Returns
         (hidden [n,hidden] | None, logits_last [vocab] | None)."""
         pos = position_ids.to(self.device, torch.int32).contiguous()
@@ -124,8 +132,22 @@ class Qwen2VLTextEngine:
         emb = None if inputs_embeds is None else inputs_embeds.to(self.device, torch.bfloat16).contiguous()
         hid = torch.empty(n, self.config.hidden_size, dtype=torch.bfloat16, device=self.device) if want_hidden else None
         lg = torch.empty(self.config.vocab_size, dtype=torch.bfloat16, device=self.device) if want_logits else None
-        _hip.check(self._L.td_qwen2_forward(self._h, _hip.ptr(tok), _hip.ptr(emb), _hip.ptr(pos), n, pos0,
-                                            _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
+        _hip.check(self._L.td_qwen2_forward_slot(self._h, slot, _hip.ptr(tok), _hip.ptr(emb), _hip.ptr(pos), n, pos0,
+                                                 _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
+        return hid, lg
+
+    def decode_batch(self, token_ids, position_ids, cache_pos: Sequence[int], want_logits=True):
+        """One token for each of the sequences in slots 0..B-1 in a single pass over the weights.
+        token_ids [B], position_ids [3,B], cache_pos[b] = tokens already cached.  -> (hidden [B,hidden], logits [B,vocab] | None)."""
+        B = len(cache_pos)
+        tok = torch.as_tensor(token_ids, dtype=torch.int32).to(self.device).contiguous()
+        pos = torch.as_tensor(position_ids, dtype=torch.int32).to(self.device).contiguous()
+        assert tok.shape == (B,) and pos.shape == (3, B)
+        hid = torch.empty(B, self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
+        lg = torch.empty(B, self.config.vocab_size, dtype=torch.bfloat16, device=self.device) if want_logits else None
+        cp = (ctypes.c_int * B)(*[int(c) for c in cache_pos])
+        _hip.check(self._L.td_qwen2_decode_batch(self._h, B, _hip.ptr(tok), _hip.ptr(pos), ctypes.cast(cp, ctypes.c_void_p),
+                                                 _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
         return hid, lg
 
     # ---- multimodal prompt assembly ([ext] vLLM Qwen2-VL input processor + transformers Qwen2VLModel.get_rope_index) ----
@@ -215,6 +237,92 @@ class Qwen2VLTextEngine:
                 break
         hs = torch.cat(out_hidden) if out_hidden else torch.empty(0, self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
         return {"prompt_hidden_states": prompt_hidden, "hidden_states": hs, "token_ids": out_ids}
+
+    MAX_BATCH = 16
+
+    @torch.no_grad()
+    def generate_batch(self, requests: Sequence[dict], sampling: SamplingParams, eos_token_id: Optional[int] = None,
+                       generator: Optional[torch.Generator] = None, forced_output_ids: Optional[Sequence[Sequence[int]]] = None):
+        """`generate` for up to min(16, n_slots) requests together: each prompt is prefilled into its own cache slot, then
+        every decode step advances all unfinished sequences in one pass over the weights (what vLLM's batching gives the
+        reference's precompute job).  requests: dicts with "prompt_token_ids" and optional "position_ids" / "inputs_embeds".
+        Returns one generate()-style dict per request, in order."""
+        B = len(requests)
+        if B > min(self.MAX_BATCH, getattr(self, "n_slots", 1)):
+            raise _hip.ThinkDiffHipError(f"generate_batch: {B} requests exceed min({self.MAX_BATCH}, n_slots={getattr(self, 'n_slots', 1)}); call set_slots first")
+        res = [{"prompt_hidden_states": None, "hidden_states": [], "token_ids": []} for _ in range(B)]
+        cache_len, next_pos, rows = [], [], []
+        for b, r in enumerate(requests):
+            ids = list(r["prompt_token_ids"])
+            pos = self.text_position_ids(len(ids)) if r.get("position_ids") is None else r["position_ids"]
+            emb = r.get("inputs_embeds")
+            hid, lg = self.forward(pos, torch.tensor(ids, dtype=torch.int32) if emb is None else None, emb, 0, True, True, slot=b)
+            res[b]["prompt_hidden_states"] = hid
+            cache_len.append(len(ids))
+            next_pos.append(int(pos.max()) + 1)
+            rows.append(lg)
+        logits = torch.stack(rows)                  # [B, vocab], row i belongs to the sequence in slot i
+        owner = list(range(B))                      # slot -> request index
+        stops = set(sampling.stop_token_ids or [])
+        step = 0
+        while owner and step < sampling.max_tokens:
+            n = len(owner)
+            if forced_output_ids is not None:
+                live = [i for i in range(n) if step < len(forced_output_ids[owner[i]])]
+                if len(live) < n:                   # forced continuations of different lengths: retire the exhausted ones first
+                    self._compact(owner, cache_len, next_pos, live)
+                    logits = logits[live]
+                    if not owner:
+                        break
+                    n = len(owner)
+                toks = [int(forced_output_ids[owner[i]][step]) for i in range(n)]
+            else:
+                toks = self._sample_batch(logits[:n], sampling, generator)
+            pos = torch.tensor([[next_pos[i] for i in range(n)]] * 3, dtype=torch.int32)
+            hid, logits = self.decode_batch(toks, pos, cache_len[:n])
+            keep = []
+            for i in range(n):
+                r = res[owner[i]]
+                r["token_ids"].append(toks[i])
+                r["hidden_states"].append(hid[i:i + 1])
+                cache_len[i] += 1
+                next_pos[i] += 1
+                done_eos = (not sampling.ignore_eos) and eos_token_id is not None and toks[i] == eos_token_id
+                stop = forced_output_ids is None and step + 1 >= sampling.min_tokens and (done_eos or toks[i] in stops)
+                if not stop and cache_len[i] < self.slot_len:
+                    keep.append(i)
+            if len(keep) < n:
+                self._compact(owner, cache_len, next_pos, keep)
+                logits = logits[keep]
+            step += 1
+        for r in res:
+            r["hidden_states"] = (torch.cat(r["hidden_states"]) if r["hidden_states"]
+                                  else torch.empty(0, self.config.hidden_size, dtype=torch.bfloat16, device=self.device))
+        return res
+
+    def _compact(self, owner, cache_len, next_pos, keep):
+        """Keep the sequences at slot indices `keep` (ascending) and pack them into slots 0..len(keep)-1."""
+        for dst, src in enumerate(keep):
+            if dst != src:
+                _hip.check(self._L.td_qwen2_move_slot(self._h, src, dst, cache_len[src], _hip.stream_ptr()))
+        owner[:] = [owner[i] for i in keep]
+        cache_len[:] = [cache_len[i] for i in keep]
+        next_pos[:] = [next_pos[i] for i in keep]
+
+    @staticmethod
+    def _sample_batch(logits: torch.Tensor, sp: SamplingParams, generator=None) -> List[int]:
+        """Row-wise temperature / top-p sampling on the device, one host round trip for the whole batch."""
+        x = logits.float()
+        if sp.temperature <= 0:
+            return x.argmax(dim=-1).tolist()
+        probs = torch.softmax(x / sp.temperature, dim=-1)
+        if sp.top_p < 1.0:
+            sp_, idx = torch.sort(probs, dim=-1, descending=True)
+            keep = (torch.cumsum(sp_, -1) - sp_) < sp.top_p
+            sp_ = torch.where(keep, sp_, torch.zeros_like(sp_))
+            pick = torch.multinomial(sp_ / sp_.sum(-1, keepdim=True), 1, generator=generator)
+            return idx.gather(1, pick)[:, 0].tolist()
+        return torch.multinomial(probs, 1, generator=generator)[:, 0].tolist()
 
     @staticmethod
     def _sample(logits: torch.Tensor, sp: SamplingParams, generator=None) -> int:

@@ -107,6 +107,52 @@ def bench_gemmsmall():
         del pool
 
 
+def bench_batch3():
+    """Would true batching of 3 images (M = 3 x 4289 rows per GEMM, attention batch 3) beat 3 separate launches?  Cold weights."""
+    S = 4289
+    tot1 = tot3 = 0.0
+    for name, N, K, count in [("qkv", 9216, 3072, 19), ("out", 3072, 3072, 19), ("ff1", 12288, 3072, 19), ("ff2", 3072, 12288, 19),
+                              ("W1", 21504, 3072, 38), ("W2", 3072, 15360, 38)]:
+        x1 = torch.randn(S, K, device="cuda").bfloat16()
+        x3 = torch.randn(3 * S, K, device="cuda").bfloat16()
+        npool = max(2, int(1.2e9 // (N * K * 2)))
+        pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(npool)]
+        b = torch.randn(N, device="cuda").bfloat16()
+        y1 = torch.empty(S, N, device="cuda", dtype=torch.bfloat16)
+        y3 = torch.empty(3 * S, N, device="cuda", dtype=torch.bfloat16)
+        st = {"i": 0}
+        def f1():
+            st["i"] = (st["i"] + 1) % npool
+            for _ in range(3):
+                _hip.linear(x1, pool[st["i"]], b, out=y1)
+        def f3():
+            st["i"] = (st["i"] + 1) % npool
+            _hip.linear(x3, pool[st["i"]], b, out=y3)
+        t1 = min(timeit(f1, iters=6, warmup=2) for _ in range(3))
+        t3 = min(timeit(f3, iters=6, warmup=2) for _ in range(3))
+        fl = 2.0 * 3 * S * N * K
+        print(f"{name:4s} N={N:5d} K={K:5d}: 3 launches {t1*1e3:7.1f} us ({fl/t1/1e9:6.0f} TF/s)   one M=3S launch {t3*1e3:7.1f} us ({fl/t3/1e9:6.0f} TF/s)   x{t1/t3:.3f}", flush=True)
+        tot1 += t1 * count; tot3 += t3 * count
+        del pool
+    H = 24
+    q1 = torch.randn(1, S, 3 * H * 128, device="cuda").bfloat16()
+    q3 = torch.randn(3, S, 3 * H * 128, device="cuda").bfloat16()
+    o1 = torch.empty(1, S, H * 128, device="cuda", dtype=torch.bfloat16)
+    o3 = torch.empty(3, S, H * 128, device="cuda", dtype=torch.bfloat16)
+    W = H * 128
+    def a1():
+        for _ in range(3):
+            _hip.attention(q1[:, :, :W], q1[:, :, W:2 * W], q1[:, :, 2 * W:], o1, H, H)
+    def a3():
+        _hip.attention(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], o3, H, H)
+    t1 = min(timeit(a1, iters=6, warmup=2) for _ in range(3))
+    t3 = min(timeit(a3, iters=6, warmup=2) for _ in range(3))
+    fl = 3 * 4.0 * S * S * H * 128
+    print(f"attention: 3 launches {t1*1e3:7.1f} us ({fl/t1/1e9:6.0f} TF/s)   batch-3 launch {t3*1e3:7.1f} us ({fl/t3/1e9:6.0f} TF/s)   x{t1/t3:.3f}", flush=True)
+    tot1 += t1 * 57; tot3 += t3 * 57
+    print(f"per step (3 images): separate {tot1:.1f} ms, batched {tot3:.1f} ms  -> x{tot1/tot3:.3f}; per image per 28 steps {tot1*28/3:.0f} vs {tot3*28/3:.0f} ms")
+
+
 def bench_gemmcold():
     """Tile/pipeline variants with L3-warm weights (one W re-used) vs cold weights (cycling a 1 GB pool, as in
     the real denoise loop where every layer's weights stream from HBM).  Interleaved rounds, best-of."""
