@@ -181,3 +181,29 @@ def test_batched_decode_equals_one_sequence_at_a_time(hip):
     for r, o in zip(reqs[:3], gb):
         ref = e.generate(r["prompt_token_ids"], sp0, position_ids=r.get("position_ids"))
         assert o["token_ids"] == ref["token_ids"] and _rel(o["hidden_states"], ref["hidden_states"]) < 5e-3
+
+
+def test_get_embed_batches_requests(hip):
+    """get_embed over several requests with max_num_seqs > 1 runs them through generate_batch: same aligner inputs as one
+    request at a time (teacher-forced)."""
+    from oracle import aligner_ref as A
+    from thinkdiff.models.mllama_vllm_t5_embed_decoder_2 import MllamaVllmT5EmbedDecoderForConditionalGeneration_5
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=9)
+    asd = A.init_weights(cfg.hidden, 4096, seed=4)
+    tc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
+                           num_key_value_heads=cfg.num_kv_heads, intermediate_size=cfg.intermediate, vocab_size=cfg.vocab)
+    outs = {}
+    for nseq in (1, 4):
+        m = MllamaVllmT5EmbedDecoderForConditionalGeneration_5(tc, vllm_config={"max_model_len": 256, "max_tokens": 8, "min_tokens": 8, "max_num_seqs": nseq})
+        m.mllama.load_state_dict(sd)
+        m.load_state_dict(asd)
+        g = torch.Generator().manual_seed(1)
+        reqs = [{"prompt_token_ids": torch.randint(0, cfg.vocab, (n,), generator=g).tolist()} for n in (20, 33, 7)]
+        forced = [torch.randint(0, cfg.vocab, (8,), generator=g).tolist() for _ in reqs]
+        outs[nseq] = m.get_embed(reqs, embedding_type="both", need_process=False, forced_output_ids=forced)
+        torch.cuda.synchronize()
+    for a, b, n in zip(outs[1][0], outs[4][0], (20, 33, 7)):
+        assert a.shape == b.shape == (n + 8, 4096) and _rel(b, a) < 5e-3
+    assert outs[1][1] == outs[4][1]

@@ -38,7 +38,9 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(QwenChatFrontend, BaseM
         self.config = SimpleNamespace(vllm_config=vc, mm_projector_type=mm_projector_type,
                                       mm_hidden_size=(text_config or Qwen2VLTextConfig()).hidden_size, hidden_size=hidden_size)
         self._device = torch.device(device)
-        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device)
+        # vLLM decodes up to `max_num_seqs` requests together; here up to 16 sequences share each pass over the weights
+        self.decode_batch = max(1, min(Qwen2VLTextEngine.MAX_BATCH, int(vc.get("max_num_seqs", 1))))
+        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch)
         self.mllama_sampling_params = SamplingParams(
             temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 128),
             min_tokens=vc.get("min_tokens", 128), ignore_eos=vc.get("ignore_eos", True))
@@ -81,13 +83,18 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(QwenChatFrontend, BaseM
         decoded text when a tokenizer is loaded, else the generated token ids as a space-separated string."""
         reqs = self._to_requests(mllama_inputs, need_process)
         sp = self.mllama_sampling_params    # **generate_kwargs (e.g. the drivers' max_new_tokens=128) are accepted and unused, as in the reference (:1019-1118)
+        reqs = [self.resolve_request(r) for r in reqs]
         outs = []
-        for i, r in enumerate(reqs):
-            r = self.resolve_request(r)
-            ids = list(r["prompt_token_ids"])
-            forced = None if forced_output_ids is None else forced_output_ids[i]
-            outs.append(self.mllama.generate(ids, sp, position_ids=r.get("position_ids"),
-                                             inputs_embeds=r.get("inputs_embeds"), generator=generator, forced_output_ids=forced))
+        if self.decode_batch > 1 and len(reqs) > 1:
+            for c0 in range(0, len(reqs), self.decode_batch):
+                chunk = reqs[c0:c0 + self.decode_batch]
+                forced = None if forced_output_ids is None else list(forced_output_ids[c0:c0 + self.decode_batch])
+                outs.extend(self.mllama.generate_batch(chunk, sp, generator=generator, forced_output_ids=forced))
+        else:
+            for i, r in enumerate(reqs):
+                forced = None if forced_output_ids is None else forced_output_ids[i]
+                outs.append(self.mllama.generate(list(r["prompt_token_ids"]), sp, position_ids=r.get("position_ids"),
+                                                 inputs_embeds=r.get("inputs_embeds"), generator=generator, forced_output_ids=forced))
         inp = [o["prompt_hidden_states"] for o in outs]
         out = [o["hidden_states"] for o in outs]
         if embedding_type == "both":
