@@ -8,7 +8,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 template <int SHAPE>
 __global__ __launch_bounds__(512) void k(float* out, int iters, unsigned seed) {
   bf16x8_t a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + ((threadIdx.x * 7 + i * 13 + seed) & 0x7f)); b[i] = (short)(0x3f00 + ((threadIdx.x * 11 + i * 5 + seed) & 0x7f)); }
+  for (int i = 0; i < 8; ++i) {
+    unsigned h = (threadIdx.x * 2654435761u) ^ (i * 40503u) ^ (seed * 97u) ^ (blockIdx.x * 7919u);
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    a[i] = (short)(0x3c00 + (h & 0x3ff) + ((h >> 16) & 0x8000));          // random sign / mantissa, exponent near 0
+    b[i] = (short)(0x3c00 + ((h >> 10) & 0x3ff) + ((h >> 17) & 0x8000));
+  }
   float s = 0.f;
   if constexpr (SHAPE == 16) {
     f32x4_t acc[16];
@@ -19,15 +24,13 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, unsigned seed) {
     }
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
   } else {
-    f32x16_t acc[4];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    f32x16_t acc[8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
     }
-    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
   }
   if (s == 123.456f) out[0] = s;
 }
