@@ -144,7 +144,8 @@ def test_linear_tile_288x192(hip, M, N, K):
     _close(y, _ref_linear(x, w, b, act=1), 2.0 ** -6)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 3584, 18944), (1, 4608, 3584), (2, 152064, 256), (3, 1024, 3072), (5, 40, 1408), (8, 3072, 768), (1, 8, 64)])
+@pytest.mark.parametrize("M,N,K", [(1, 3584, 18944), (1, 4608, 3584), (2, 152064, 256), (3, 1024, 3072), (5, 40, 1408), (8, 3072, 768), (1, 8, 64),
+                                   (16, 3584, 18944), (13, 4608, 3584), (9, 37888, 1536), (6, 48, 64), (16, 151936, 1536)])
 @pytest.mark.parametrize("mode", ["bias", "act", "gate_res", "none"])
 def test_skinny_m_weight_stream_kernel(hip, M, N, K, mode):
     """M <= 8 routes to csrc/gemv_bf16.hip (td_gemv_bf16_kernel): same epilogue semantics as the tile kernel."""

@@ -112,11 +112,86 @@ __global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParam
   else p.C[(size_t)m * p.ldc + n] = f2bf(v);
 }
 
+// ---- 4 < M <= 16: the same weight stream on the matrix core ---------------------------------------------------------
+// With more activation rows the dot-product form re-reads x from L2 MR times per weight chunk (at M = 16 x traffic is 8x the
+// weight traffic and the kernel stops scaling).  Here a workgroup owns 16 weight rows, its 8 waves split K in 64-element steps,
+// and every step is two v_mfma_f32_16x16x32_bf16 with the weight rows as the A operand and the (<= 16) activation rows as the
+// B operand -- both fragments are loaded straight from global memory in MFMA operand layout (lane = row, 16 B of k), so x
+// traffic equals weight traffic and there is no VALU work in the loop.  Accumulators are reduced across waves through LDS.
+constexpr int MW = 8;   // waves per workgroup (K split)
+
+__global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParams p) {
+  __shared__ float red[MW][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const bf16_t* wrow = p.W + (size_t)min(n0 + r, p.N - 1) * p.K + 8 * g;
+  const bf16_t* xrow = p.A + (size_t)min(r, p.M - 1) * p.lda + 8 * g;
+  const int nk = p.K >> 6;                      // 64-element steps
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  int s = wid;
+  for (; s + MW < nk; s += 2 * MW) {            // two steps in flight: 4 weight + 4 activation loads per lane
+    const bf16x8_t w0 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64));
+    const bf16x8_t w1 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64 + 32));
+    const bf16x8_t w2 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)(s + MW) * 64));
+    const bf16x8_t w3 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)(s + MW) * 64 + 32));
+    const bf16x8_t x0 = *(const bf16x8_t*)(xrow + (size_t)s * 64);
+    const bf16x8_t x1 = *(const bf16x8_t*)(xrow + (size_t)s * 64 + 32);
+    const bf16x8_t x2 = *(const bf16x8_t*)(xrow + (size_t)(s + MW) * 64);
+    const bf16x8_t x3 = *(const bf16x8_t*)(xrow + (size_t)(s + MW) * 64 + 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3, x3, acc, 0, 0, 0);
+  }
+  if (s < nk) {
+    const bf16x8_t w0 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64));
+    const bf16x8_t w1 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64 + 32));
+    const bf16x8_t x0 = *(const bf16x8_t*)(xrow + (size_t)s * 64);
+    const bf16x8_t x1 = *(const bf16x8_t*)(xrow + (size_t)s * 64 + 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wid][lane][i] = acc[i];
+  __syncthreads();
+  if (wid != 0) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < MW; ++w)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += red[w][lane][i];
+  // C layout of the MFMA: column (lane & 15) = activation row m, rows 4 (lane >> 4) + i = weight rows n
+  const int m = r, n = n0 + 4 * g;
+  if (m >= p.M || n >= p.N) return;
+  const bool second = p.C2 != nullptr && n >= p.n_split;
+  const int act = second ? p.act2 : p.act;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float y = v[i];
+    if (p.bias) y += bf2f(p.bias[n + i]);
+    if (act != TD_ACT_NONE) y = act_rt(act, rbf(y));
+    else {
+      if (p.gate) y = rbf(y) * bf2f(p.gate[n + i]);
+      if (p.res) y = rbf(y) + bf2f(p.res[(size_t)m * p.ldr + n + i]);
+    }
+    v[i] = y;
+  }
+  const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  if (second) *(u32x2_t*)(p.C2 + (size_t)m * p.ldc2 + (n - p.n_split)) = o;
+  else *(u32x2_t*)(p.C + (size_t)m * p.ldc + n) = o;
+}
+
 }  // namespace
 
 int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M >= 1 && p.M <= 16 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 16, N %% 4 == 0, K %% 8 == 0");
   TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W) % 16 == 0, "td_gemv: operands must be 16-byte aligned");
+  if (p.M > 4 && p.K % 64 == 0 && p.N % 16 == 0 && p.ldc % 4 == 0 && (!p.C2 || (p.ldc2 % 4 == 0 && p.n_split % 4 == 0)) && (!p.res || p.ldr % 1 == 0)) {
+    hipLaunchKernelGGL(td_gemv_mfma_kernel, dim3(p.N / 16), dim3(MW * 64), 0, stream, p);
+    TD_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(p.N / R), block(THREADS);
   if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, grid, block, 0, stream, p);
   else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, grid, block, 0, stream, p);
