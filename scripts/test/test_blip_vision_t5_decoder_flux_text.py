@@ -61,6 +61,8 @@ class ClipFluxDriver:
             raise FileNotFoundError("no FLUX weights: set run.local_weights.flux to a local diffusers directory or run.synthetic: true")
         self.text = providers.load_text_encoders(run, self.pipe, self.device)
         self.pipe.set_progress_bar_config(disable=True)
+        from concurrent.futures import ThreadPoolExecutor
+        self._saver, self._pending_saves = ThreadPoolExecutor(max_workers=2), []
         self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"))   # "fp8": BASELINE config 5's e4m3 block GEMMs
 
     # ---- config surface (reference :117-161) ---------------------------------------------------------------
@@ -126,11 +128,21 @@ class ClipFluxDriver:
                                num_images_per_prompt=1, height=run["flux_height"], width=run["flux_width"], latents=lat,
                                num_inference_steps=run["flux_num_inference_steps"], guidance_scale=run["guidance_scale"]).images
         for img, (_, _, out_path) in zip(images, jobs):
-            img.save(out_path, format="PNG", compress_level=1)
-            print(f"Image saved to {out_path}")
+            self._pending_saves.append(self._saver.submit(self._save_png, img, out_path))   # PNG encoding overlaps the next group's GPU work
+
+    @staticmethod
+    def _save_png(img, out_path):
+        img.save(out_path, format="PNG", compress_level=1)        # reference :247 / :322
+        print(f"Image saved to {out_path}")
 
     def render(self, img_url, prompt, out_path):
         self.render_group([(img_url, prompt, out_path)])
+        self._drain_saves()
+
+    def _drain_saves(self):
+        for f in self._pending_saves:
+            f.result()
+        self._pending_saves.clear()
 
     def run(self):
         run = self.cfg.run_cfg
@@ -161,6 +173,7 @@ class ClipFluxDriver:
                 if len(pending) == G:
                     flush()
         flush()
+        self._drain_saves()
         return written
 
 
