@@ -62,6 +62,15 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         prompt = texts[i]
         return {"prompt": prompt, "prompt_token_ids": self.mllama_tokenizer.encode(prompt, add_special_tokens=False)}
 
+    def _requests(self, samples: dict, idx) -> List[dict]:
+        """The requests of one decode chunk; with the chat front end loaded, their images share one vision-tower call."""
+        if self.request_builder is not None or self.mllama_processor is None or self.mllama_tokenizer is None:
+            return [self._request(samples, i) for i in idx]
+        texts = samples["answers"] if self.config.text_input_key is None else samples[self.config.text_input_key]
+        images = samples.get("images", None)
+        idx = list(idx)
+        return self.resolve_requests(self.chat_requests([texts[i] for i in idx], [images[i] if images is not None else None for i in idx]))
+
     @torch.no_grad()
     def forward_inner(self, mllama_inputs: dict, generator=None) -> Dict:
         n = len(mllama_inputs["images"]) if "images" in mllama_inputs else len(mllama_inputs["answers"])
@@ -69,7 +78,7 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         tok = {"input_prompt": [], "input_prompt_token_ids": [], "output_text": [], "output_token_ids": []}
         out_embed, in_embed, texts = [], [], []
         for c0 in range(0, n, self.decode_batch):
-            reqs = [self._request(mllama_inputs, i) for i in range(c0, min(c0 + self.decode_batch, n))]
+            reqs = self._requests(mllama_inputs, range(c0, min(c0 + self.decode_batch, n)))
             outs = self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator)
             for r, o in zip(reqs, outs):
                 text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))

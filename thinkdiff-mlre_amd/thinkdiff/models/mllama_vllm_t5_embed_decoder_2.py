@@ -83,7 +83,7 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(QwenChatFrontend, BaseM
         decoded text when a tokenizer is loaded, else the generated token ids as a space-separated string."""
         reqs = self._to_requests(mllama_inputs, need_process)
         sp = self.mllama_sampling_params    # **generate_kwargs (e.g. the drivers' max_new_tokens=128) are accepted and unused, as in the reference (:1019-1118)
-        reqs = [self.resolve_request(r) for r in reqs]
+        reqs = self.resolve_requests(reqs)
         outs = []
         if self.decode_batch > 1 and len(reqs) > 1:
             for c0 in range(0, len(reqs), self.decode_batch):

@@ -375,6 +375,45 @@ class QwenChatFrontend:
         emb[mask.to(emb.device)] = merged
         return ids, emb, Qwen2VLTextEngine.mrope_position_ids(ids, grid, merge, self.image_token_id)
 
+    def resolve_requests(self, reqs: Sequence[dict]) -> List[dict]:
+        """resolve_request for a batch: all images of the batch go through the image processor and the vision tower in ONE
+        call (the tower's GEMMs then see thousands of patch rows instead of one image's few hundred)."""
+        out = [dict(r) for r in reqs]
+        for r in out:
+            if "prompt_token_ids" not in r:
+                if self.mllama_tokenizer is None:
+                    raise _hip.ThinkDiffHipError("request has no 'prompt_token_ids' and no tokenizer is loaded")
+                r["prompt_token_ids"] = self.mllama_tokenizer.encode(r["prompt"], add_special_tokens=False)
+        need = [i for i, r in enumerate(out) if (r.get("multi_modal_data") or {}).get("image") is not None and "inputs_embeds" not in r]
+        if not need:
+            return out
+        if self.visual is None or self.image_processor is None:
+            raise _hip.ThinkDiffHipError("image request: load the vision tower (visual=HipQwen2VisionTransformer...) and an "
+                                         "image_processor, or supply 'inputs_embeds' and 'position_ids' with the request")
+        per_req = []
+        for i in need:
+            im = out[i]["multi_modal_data"]["image"]
+            per_req.append(list(im) if isinstance(im, (list, tuple)) else [im])
+        feats = self.image_processor(images=[im for ims in per_req for im in ims], return_tensors="pt")
+        grid = feats["image_grid_thw"].tolist()
+        merged = self.visual(feats["pixel_values"], grid).pooler_output
+        merge = self.visual.merge
+        counts = [t * h * w // (merge * merge) for t, h, w in grid]
+        g0 = m0 = 0
+        for i, ims in zip(need, per_req):
+            r = out[i]
+            g = grid[g0:g0 + len(ims)]
+            n_tok = sum(counts[g0:g0 + len(ims)])
+            ids = Qwen2VLTextEngine.expand_image_placeholders(list(r["prompt_token_ids"]), g, merge, self.image_token_id)
+            emb = self.mllama.embed_tokens(ids)
+            mask = torch.tensor(ids) == self.image_token_id
+            emb[mask.to(emb.device)] = merged[m0:m0 + n_tok]
+            r["prompt_token_ids"], r["inputs_embeds"] = ids, emb
+            r["position_ids"] = Qwen2VLTextEngine.mrope_position_ids(ids, g, merge, self.image_token_id)
+            g0 += len(ims)
+            m0 += n_tok
+        return out
+
     def resolve_request(self, r: dict) -> dict:
         """Fill prompt_token_ids (tokenizer) and, for image requests, inputs_embeds + position_ids."""
         r = dict(r)
