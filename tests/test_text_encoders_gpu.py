@@ -24,17 +24,20 @@ def test_t5_encoder_matches_transformers(hip):
     with torch.no_grad():
         for p in ref.parameters():
             p.mul_(3.0)           # default init is tiny: make attention / bias matter
-    ref = ref.bfloat16()
     ids = torch.randint(0, 512, (2, 128))
+    ref = ref.bfloat16()
     with torch.no_grad():
         want = ref(input_ids=ids)[0]
+        exact = ref.float()(input_ids=ids)[0]          # the same (bf16-valued) weights in exact arithmetic
+    ref = ref.bfloat16()
     enc = HipT5Encoder(ref.state_dict(), num_heads=4, d_kv=64)
     got = enc(ids, output_hidden_states=False)[0]
     torch.cuda.synchronize()
     assert got.shape == want.shape == (2, 128, 256)
-    e = _rel(got, want)
-    print(f"T5 rel-RMSE {e:.4f}")
+    e, e32, eref = _rel(got, want), _rel(got, exact), _rel(want, exact)
+    print(f"T5 rel-RMSE hip~bf16 {e:.4f}  hip~fp32 {e32:.4f}  bf16~fp32 {eref:.4f}")
     assert e < 2e-2
+    assert e32 < 1.2 * eref + 1e-3       # no further from exact arithmetic than the bf16 torch model itself is
 
 
 def test_clip_text_encoder_matches_transformers(hip):
