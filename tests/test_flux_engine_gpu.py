@@ -138,3 +138,43 @@ def test_images_in_flight_are_bit_identical_to_sequential(hip):
         assert torch.equal(outs[prec, 1], outs[prec, 2]) and torch.equal(outs[prec, 1], outs[prec, 3])
         assert not torch.equal(outs[prec, 1][0], outs[prec, 1][1])
     assert not torch.equal(outs["bf16", 1], outs["fp8", 1])
+
+
+def test_full_width_full_sequence_block_pair(hip):
+    """FLUX.1-dev width (24 heads x 128, MLP 12288, joint dim 4096) at BASELINE config 2's token counts (4096 image + 193 text
+    tokens = the ragged 4289-row case every hot GEMM / attention launch sees), one double- and one single-stream block:
+    bf16 engine vs the bf16 oracle and the exact-arithmetic oracle, fp8 engine vs the fp8 oracle."""
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1, num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768)
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig
+    sd = R.init_weights(cfg, seed=21)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=1, num_single_layers=1), max_img_tokens=4096, max_txt_tokens=256, max_steps=4)
+    m.load_state_dict(sd)
+    h2 = w2 = 64
+    T = 193
+    lat, pe, pool = _inputs(cfg, h2, w2, T, seed=5)
+    img_ids, txt_ids = R.latent_image_ids(h2, w2), torch.zeros(T, 3)
+    t, g = torch.tensor([0.7324]), torch.tensor([3.5])
+    args = (sd, cfg, lat, pe, pool, t.bfloat16(), img_ids.bfloat16(), txt_ids.bfloat16(), g)
+    ref16 = R.transformer_forward(*args)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    ref32 = R.transformer_forward(sd32, cfg, lat.float(), pe.float(), pool.float(), t.bfloat16().float(), img_ids, txt_ids,
+                                  torch.tensor([float((g.bfloat16() * 1000).float()) / 1000]))
+    R.FP8_BLOCK_LINEARS = True
+    try:
+        ref8 = R.transformer_forward(*args)
+    finally:
+        R.FP8_BLOCK_LINEARS = False
+    out16 = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0].clone()
+    m.set_precision("fp8")
+    out8 = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0].clone()
+    torch.cuda.synchronize()
+    e16, e32, eref, e88 = _rel_rmse(out16, ref16), _rel_rmse(out16, ref32), _rel_rmse(ref16, ref32), _rel_rmse(out8, ref8)
+    print(f"full width S=4289: hip~bf16-oracle {e16:.4f}  hip~fp32-oracle {e32:.4f}  bf16-oracle~fp32-oracle {eref:.4f}  hip-fp8~oracle-fp8 {e88:.4f}  "
+          f"fp8~bf16 hip {_rel_rmse(out8, out16):.4f} oracle {_rel_rmse(ref8, ref16):.4f}")
+    assert out16.shape == (1, 4096, 64)
+    assert e16 < 2e-2 and e32 < 1.5 * eref + 2e-3
+    # fp8: the two pipelines feed e4m3 quantisers inputs that differ by bf16 noise, so a few per cent of the elements land on
+    # the other side of a rounding boundary; the bar is therefore relative to the size of the fp8 effect itself: the engine
+    # must be closer to the fp8 oracle than fp8 is to bf16, deviate from bf16 as much as the oracle says it should, and <= 5e-2
+    d_hip, d_ref = _rel_rmse(out8, out16), _rel_rmse(ref8, ref16)
+    assert e88 < 5e-2 and e88 < 0.75 * d_hip and abs(d_hip - d_ref) < 0.25 * d_ref
