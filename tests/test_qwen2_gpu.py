@@ -207,3 +207,37 @@ def test_get_embed_batches_requests(hip):
     for a, b, n in zip(outs[1][0], outs[4][0], (20, 33, 7)):
         assert a.shape == b.shape == (n + 8, 4096) and _rel(b, a) < 5e-3
     assert outs[1][1] == outs[4][1]
+
+
+def test_full_width_qwen2_7b_layers(hip):
+    """Qwen2-VL-7B layer shapes (hidden 3584, 28 q / 4 kv heads, MLP 18944), two layers: prefill of 300 tokens with an
+    image-like M-RoPE block, then decode one sequence at a time (weight-stream kernel, M = 1) and 9 sequences per pass
+    (matrix-core skinny GEMM, M = 9) against the oracle on the same teacher-forced ids."""
+    from thinkdiff.models.qwen2_vl import SamplingParams
+    cfg = Q.tiny_config(hidden=3584, num_layers=2, num_heads=28, num_kv_heads=4, intermediate=18944, vocab=4096)
+    sd = Q.init_weights(cfg, seed=31)
+    e = _engine(cfg, sd, max_len=512)
+    g = torch.Generator().manual_seed(6)
+    n, k = 300, 6
+    ids = torch.randint(0, cfg.vocab, (n + k,), generator=g)
+    pos = torch.stack([torch.arange(n + k), torch.arange(n + k) // 3 + 2, (torch.arange(n + k) * 2) % 11]).to(torch.int32)
+    pos[:, n:] = pos[:, :n].max() + 1 + torch.arange(k, dtype=torch.int32)          # generation continues past the largest position
+    ref, _ = Q.text_model_hidden(sd, cfg, pos, token_ids=ids)
+    sp = SamplingParams(max_tokens=k, min_tokens=k, ignore_eos=True)
+    one = e.generate(ids[:n].tolist(), sp, position_ids=pos[:, :n], forced_output_ids=ids[n:].tolist())
+    torch.cuda.synchronize()
+    e_pre, e_dec = _rel(one["prompt_hidden_states"], ref[:n]), _rel(one["hidden_states"], ref[n:])
+    e2 = type(e)(e.config, max_model_len=512, n_slots=9)
+    e2.load_state_dict(sd)
+    reqs = [{"prompt_token_ids": ids[:n].tolist(), "position_ids": pos[:, :n]}] + \
+           [{"prompt_token_ids": torch.randint(0, cfg.vocab, (40 + 7 * b,), generator=g).tolist()} for b in range(8)]
+    forced = [ids[n:].tolist()] + [torch.randint(0, cfg.vocab, (k,), generator=g).tolist() for _ in range(8)]
+    many = e2.generate_batch(reqs, sp, forced_output_ids=forced)
+    torch.cuda.synchronize()
+    e_bat = _rel(many[0]["hidden_states"], ref[n:])
+    ref32, _ = Q.text_model_hidden({k_: v.float() for k_, v in sd.items()}, cfg, pos, token_ids=ids)
+    e32, eref = _rel(torch.cat([one["prompt_hidden_states"], one["hidden_states"]]), ref32), _rel(ref, ref32)
+    print(f"7B-width layers: prefill {e_pre:.4f}  decode M=1 {e_dec:.4f}  decode M=9 {e_bat:.4f}   hip~fp32 {e32:.4f}  bf16-oracle~fp32 {eref:.4f}")
+    assert e_pre < 2e-2 and e_dec < 2e-2 and e_bat < 2e-2
+    assert e32 < 1.5 * eref + 2e-3
+    assert all(o["hidden_states"].shape == (k, 3584) for o in many)
