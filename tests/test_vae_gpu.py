@@ -97,3 +97,25 @@ def test_pipeline_returns_pil_image(hip):
                pooled_prompt_embeds=torch.randn(1, fc.pooled_projection_dim, generator=g).bfloat16().cuda(),
                height=32, width=32, num_inference_steps=2, guidance_scale=3.5)
     assert out.images[0].size == (32, 32) and out.images[0].mode == "RGB"
+
+
+def test_vae_full_architecture_small_image(hip):
+    """The FLUX.1 VAE decoder architecture at full width (block_out_channels 128/256/512/512, 2 layers per block, the
+    512-channel single-head mid-block attention) on a 16x16 latent -> 128x128 image, against the oracle."""
+    from thinkdiff.models.flux_vae import AutoencoderKLConfig, AutoencoderKLDecoder
+    cfg = V.VaeConfig()
+    sd = V.init_weights(cfg, seed=3)
+    m = AutoencoderKLDecoder(AutoencoderKLConfig(), max_latent_size=(16, 16))
+    m.load_state_dict(sd)
+    h = w = 16
+    g = torch.Generator().manual_seed(11)
+    packed = (torch.randn(1, (h // 2) * (w // 2), 64, generator=g) * 0.8).bfloat16()
+    ref_img, ref_u8 = V.latents_to_image(sd, cfg, packed, h, w)
+    img = m.decode_packed(packed[0].cuda(), h, w, output_type="pt")
+    u8 = m.decode_packed(packed[0].cuda(), h, w, output_type="np")
+    torch.cuda.synchronize()
+    assert img.shape == (3, 8 * h, 8 * w) and u8.shape == (8 * h, 8 * w, 3)
+    rel = float((img.float().cpu() - ref_img[0].float()).pow(2).mean().sqrt() / ref_img.float().pow(2).mean().sqrt())
+    px = float(((u8.float().cpu() - ref_u8[0].float()) / 255).pow(2).mean().sqrt())
+    print(f"vae full architecture 16x16 latent: rel-RMSE {rel:.4f}, pixel RMSE {px:.5f}")
+    assert rel < 3e-2 and px < 1e-2
