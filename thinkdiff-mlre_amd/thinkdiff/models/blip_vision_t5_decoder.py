@@ -3,9 +3,10 @@
 Mirror of reference thinkdiff/models/blip_vision_t5_decoder.py: `build_vision_projector` (:31-61),
 `BlipVisionT5DecoderForConditionalGeneration.from_config` (:501-563) and `.forward_encoder`
 (:566-643).  The aligner and the token pooling run in libthinkdiff_hip.so (td_aligner_mlp2x_bf16,
-td_cls_avgpool2_bf16).  The EVA-ViT-g tower that produces the 257 vision tokens is SURVEY.md 8f
-"next" row 4: until it is built, `vision_model` is any callable pixel_values -> [B,257,1408] device
-tensor supplied by the caller (or pass `image_embeds=` directly).
+td_cls_avgpool2_bf16).  The EVA-ViT-g tower that produces the 257 vision tokens is
+`vision_towers.HipBlip2VisionModel` (loaded by `from_config` from a local `blip2_pretrained_model_name_or_path`
+directory, or attached by `providers.load_vision`); `vision_model` may be any callable pixel_values ->
+[B,257,1408] device tensor, and `image_embeds=` bypasses it.
 """
 import re
 from types import SimpleNamespace
