@@ -300,6 +300,12 @@ int td_qwen2_forward_slot(td_qwen2* f, int slot, const int* token_ids, const voi
 /* Batched KV-cached decode (the precompute job, mllama_vllm_generate_1.py:585: vLLM decodes its whole request batch together):
  * the cache of max_tokens rows per layer is split into n_slots sequences of max_tokens / n_slots rows. */
 int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, td_qwen2** out);   /* n_slots sequences of slot_len tokens */
+/* ... and an activation workspace of ws_rows rows (>= slot_len): the capacity of a batched prefill, B x L <= ws_rows */
+int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int ws_rows, td_qwen2** out);
+/* Prefill B right-padded sequences (row b*L + t) into slots 0..B-1 in one pass; lens[b] = real tokens (HOST ints);
+ * hidden_out bf16[B*L,hidden], logits_last bf16[B,vocab] of each sequence's last real token (either may be NULL). */
+int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                           const int* lens, void* hidden_out, void* logits_last, void* stream);
 int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache rows of an existing handle */
 int td_qwen2_slot_capacity(const td_qwen2* f);
 /* copy the first `len` cache rows of sequence src to sequence dst (compaction when a sequence finishes) */

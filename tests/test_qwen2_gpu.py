@@ -168,11 +168,12 @@ def test_batched_decode_equals_one_sequence_at_a_time(hip):
     single = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in single]
     e.set_slots(8)
     assert e.slot_len == 256
-    batch = e.generate_batch(reqs, sp, forced_output_ids=forced)
+    batch = e.generate_batch(reqs, sp, forced_output_ids=forced)        # 5 x 120 padded rows fit the 2048-row workspace: batched prefill
     torch.cuda.synchronize()
     for a, b, k in zip(single, batch, gens):
         assert b["token_ids"] == a["token_ids"] and b["hidden_states"].shape == (k, cfg.hidden)
-        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 1e-6
+        assert b["prompt_hidden_states"].shape == a["prompt_hidden_states"].shape
+        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 5e-3          # different tile schedule (M = 600 vs M = n)
         assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
     # sampled continuation: every sequence yields max_tokens tokens and hidden states, greedy = argmax of its own logits
     sp0 = SamplingParams(temperature=0.0, max_tokens=6, min_tokens=6, ignore_eos=True)

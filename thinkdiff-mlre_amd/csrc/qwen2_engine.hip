@@ -50,7 +50,8 @@ struct td_qwen2 {
   float *cosT, *sinT;
   // batched decode: the cache rows of every layer are split into n_slots sequences of slot_len rows
   int n_slots = 1, slot_len = 0, ws_rows = 0;
-  bf16_t* kvtmp = nullptr;   // [TD_QWEN2_MAX_BATCH, 2 Hkv 128] k|v rows of a decode step before they are scattered
+  bf16_t* kvtmp = nullptr;   // [ws_rows, 2 Hkv 128] k|v rows of a batched step before they are scattered to their sequences
+  bf16_t* lastrows = nullptr; // [MAX_BATCH, D] last-token rows of a batched prefill (lm_head input)
   int* ibuf = nullptr;       // device ints: kv lengths, scatter offsets
 };
 
@@ -74,6 +75,14 @@ __global__ void td_scatter_rows_kernel(const bf16_t* src, bf16_t* dst_base, cons
   if (c < W) *(u32x4_t*)(dst_base + (size_t)off[b] + c) = *(const u32x4_t*)(src + (size_t)b * W + c);
 }
 
+// row b*L + t of src -> cache row (b * slot_len + t): the k|v rows of a batched prefill go to their sequences' slots
+__global__ void td_kv_rows_to_slots_kernel(const bf16_t* src, bf16_t* dst_base, int L, int slot_len, int W) {
+  const int row = blockIdx.y;
+  const int b = row / L, t = row - b * L;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c < W) *(u32x4_t*)(dst_base + ((size_t)b * slot_len + t) * W + c) = *(const u32x4_t*)(src + (size_t)row * W + c);
+}
+
 #define TDQ_TRY(expr)         \
   do {                        \
     int _rc = (expr);         \
@@ -85,8 +94,9 @@ __global__ void td_scatter_rows_kernel(const bf16_t* src, bf16_t* dst_base, cons
 extern "C" {
 
 // KV cache of n_slots sequences x slot_len rows per layer; activation workspace for slot_len rows (the longest prefill)
-int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, td_qwen2** out) {
+int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int ws_rows, td_qwen2** out) {
   TD_CHECK_ARG(cfg && out && slot_len > 0 && n_slots > 0 && (long long)slot_len * n_slots < (1ll << 30), "td_qwen2_create: bad arguments");
+  if (ws_rows < slot_len) ws_rows = slot_len;
   const int max_tokens = slot_len * n_slots;
   TD_CHECK_ARG(cfg->head_dim == 128, "td_qwen2_create: head_dim must be 128");
   TD_CHECK_ARG(cfg->hidden % 512 == 0 && cfg->intermediate % 64 == 0, "td_qwen2_create: hidden %% 512 and intermediate %% 64 must be 0");
@@ -100,7 +110,7 @@ int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, t
   f->max_tokens = max_tokens;
   f->slot_len = slot_len;
   f->n_slots = n_slots;
-  f->ws_rows = slot_len;
+  f->ws_rows = ws_rows;
   f->layers.resize(cfg->num_layers);
 
   int64_t off = 0;
@@ -147,13 +157,13 @@ int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, t
     q_add(f, p + "post_attention_layernorm.weight", l.ln2_w, D);
   }
 
-  const int64_t n = slot_len;
+  const int64_t n = ws_rows;
   struct Req { void** p; int64_t bytes; };
   std::vector<Req> reqs = {
       {(void**)&f->h, n * D * 2}, {(void**)&f->xn, n * D * 2}, {(void**)&f->q, n * Hq * 128 * 2},
       {(void**)&f->attn, n * Hq * 128 * 2}, {(void**)&f->gu, n * 2 * I * 2}, {(void**)&f->act, n * I * 2},
       {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
-      {(void**)&f->kvtmp, (int64_t)MAX_BATCH * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4},
+      {(void**)&f->kvtmp, n * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4}, {(void**)&f->lastrows, (int64_t)MAX_BATCH * D * 2},
   };
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
@@ -310,7 +320,8 @@ int td_qwen2_forward(td_qwen2* f, const int* token_ids, const void* inputs_embed
   return td_qwen2_forward_slot(f, 0, token_ids, inputs_embeds, position_ids, n, pos0, hidden_out, logits_last, stream);
 }
 
-int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) { return td_qwen2_create_slots(cfg, max_tokens, 1, out); }
+int td_qwen2_create_slots(const TdQwen2Config* cfg, int slot_len, int n_slots, td_qwen2** out) { return td_qwen2_create_ex(cfg, slot_len, n_slots, slot_len, out); }
+int td_qwen2_create(const TdQwen2Config* cfg, int max_tokens, td_qwen2** out) { return td_qwen2_create_ex(cfg, max_tokens, 1, max_tokens, out); }
 
 // re-partition the cache rows; a sequence cannot be longer than the activation workspace the handle was created with
 int td_qwen2_set_slots(td_qwen2* f, int n_slots) {
@@ -404,6 +415,86 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
   if (logits) {
     TdGemmParams g;
     g.A = f->xn; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
+    TDQ_TRY(td_gemm_launch(g, s));
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// Prefill of B sequences in one pass: every sequence is right-padded to L tokens (row b * L + t; causal attention keeps the
+// padding from influencing real tokens), sequence b goes to cache slot b.  inputs_embeds bf16[B*L, hidden] or token_ids
+// int32[B*L]; position_ids int32[3, B*L]; lens[b] = real tokens of sequence b (HOST ints).  hidden_out bf16[B*L, hidden]
+// (rows past lens[b] are meaningless), logits_last bf16[B, vocab] of each sequence's last real token (either may be NULL).
+int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                           const int* lens, void* hidden_out, void* logits_last, void* stream) {
+  TD_CHECK_ARG(f && position_ids && lens && (token_ids || inputs_embeds), "td_qwen2_prefill_batch: null argument");
+  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && L >= 1 && L <= f->slot_len && (long long)B * L <= f->ws_rows,
+               "td_qwen2_prefill_batch: B=%d x L=%d exceeds the handle (slots %d x %d tokens, workspace %d rows)", B, L, f->n_slots, f->slot_len, f->ws_rows);
+  for (int b = 0; b < B; ++b) TD_CHECK_ARG(lens[b] >= 1 && lens[b] <= L, "td_qwen2_prefill_batch: sequence %d has %d of %d tokens", b, lens[b], L);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
+  const int QW = Hq * 128, KVW = 2 * Hkv * 128, n = B * L;
+  if (inputs_embeds) TD_CHECK_HIP(hipMemcpyAsync(f->h, inputs_embeds, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));
+  else TDQ_TRY(td_embed_gather_launch(token_ids, f->embed_w, f->h, n, D, f->cfg.vocab, s));
+  TDQ_TRY(td_mrope_table_launch(position_ids, n, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
+  TdNormParams np;
+  np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = n; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
+  TdQkRopeParams rq;
+  rq.qkv = f->q; rq.ld = QW; rq.rows = n; rq.Hq = Hq; rq.Hk = 0; rq.q_col = 0; rq.k_col = 0;
+  rq.cos = f->cosT; rq.sin = f->sinT; rq.rotate_half = 2;
+  TdQkRopeParams rk = rq;
+  rk.qkv = f->kvtmp; rk.ld = KVW; rk.Hq = Hkv;
+  for (int i = 0; i < f->cfg.num_layers; ++i) {
+    const QLayer& l = f->layers[i];
+    np.w = l.ln1_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = n; g.N = QW + KVW; g.K = D;
+      g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
+      if (QW % 256 == 0) {
+        g.cfg = n <= 32 ? -1 : (td_gemm_config_id(n, QW + KVW, D) == 1 ? 1 : 0);
+        TDQ_TRY(td_gemm_launch(g, s));
+      } else {
+        TdGemmParams a = g; a.C2 = nullptr; a.N = QW;
+        TDQ_TRY(td_gemm_launch(a, s));
+        TdGemmParams b2 = g; b2.C2 = nullptr; b2.W = l.qkv_w + (size_t)QW * D; b2.bias = l.qkv_b + QW; b2.N = KVW; b2.C = f->kvtmp; b2.ldc = KVW;
+        TDQ_TRY(td_gemm_launch(b2, s));
+      }
+    }
+    TDQ_TRY(td_qk_norm_rope_launch(rq, s));
+    TDQ_TRY(td_qk_norm_rope_launch(rk, s));
+    hipLaunchKernelGGL(td_kv_rows_to_slots_kernel, dim3((KVW / 8 + 255) / 256, n), dim3(256), 0, s, f->kvtmp, l.kv, L, f->slot_len, KVW);
+    TdAttnParams ap;
+    ap.Q = f->q; ap.ldq = QW; ap.q_bstride = (long long)L * QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW;
+    ap.kv_bstride = (long long)f->slot_len * KVW; ap.O = f->attn; ap.ldo = QW; ap.o_bstride = (long long)L * QW;
+    ap.batch = B; ap.Sq = L; ap.Skv = L; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f; ap.causal = 1; ap.causal_offset = 0;
+    TDQ_TRY(td_attn_launch(ap, s));
+    {
+      TdGemmParams g;
+      g.A = f->attn; g.lda = QW; g.W = l.o_w; g.C = f->h; g.ldc = D; g.res = f->h; g.ldr = D; g.M = n; g.N = D; g.K = QW;
+      TDQ_TRY(td_gemm_launch(g, s));
+    }
+    np.w = l.ln2_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = n; g.N = 2 * I; g.K = D;
+      TDQ_TRY(td_gemm_launch(g, s));
+      TDQ_TRY(td_silu_mul_launch(f->gu, f->act, n, I, s));
+      TdGemmParams d;
+      d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = n; d.N = D; d.K = I;
+      TDQ_TRY(td_gemm_launch(d, s));
+    }
+  }
+  np.w = f->norm_w; np.y = f->xn;
+  TDQ_TRY(td_norm_rows_launch(np, s));
+  if (hidden_out) TD_CHECK_HIP(hipMemcpyAsync(hidden_out, f->xn, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));
+  if (logits_last) {
+    for (int b = 0; b < B; ++b)
+      TD_CHECK_HIP(hipMemcpyAsync(f->lastrows + (size_t)b * D, f->xn + ((size_t)b * L + lens[b] - 1) * D, (size_t)D * 2, hipMemcpyDeviceToDevice, s));
+    TdGemmParams g;
+    g.A = f->lastrows; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits_last; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
     TDQ_TRY(td_gemm_launch(g, s));
   }
   TD_CHECK_LAUNCH();

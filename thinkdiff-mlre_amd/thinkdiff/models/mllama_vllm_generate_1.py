@@ -33,7 +33,8 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         self._device = torch.device(device)
         # vLLM decodes `max_num_seqs` requests together; here up to 16 sequences share each pass over the weights
         self.decode_batch = max(1, min(Qwen2VLTextEngine.MAX_BATCH, int(vc.get("max_num_seqs", Qwen2VLTextEngine.MAX_BATCH))))
-        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch)
+        self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch,
+                                        prefill_rows=min(int(vc.get("max_num_batched_tokens", 16384)), 16384) if self.decode_batch > 1 else None)
         self.mllama_sampling_params = SamplingParams(
             temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 256),
             min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False))

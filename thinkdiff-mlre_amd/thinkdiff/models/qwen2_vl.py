@@ -45,7 +45,8 @@ class SamplingParams:
 class Qwen2VLTextEngine:
     dtype = torch.bfloat16
 
-    def __init__(self, config: Optional[Qwen2VLTextConfig] = None, max_model_len: int = 8192, device="cuda", n_slots: int = 1, **kw):
+    def __init__(self, config: Optional[Qwen2VLTextConfig] = None, max_model_len: int = 8192, device="cuda", n_slots: int = 1,
+                 prefill_rows: Optional[int] = None, **kw):
         self.config = config or Qwen2VLTextConfig(**kw)
         c = self.config
         self.device = torch.device(device)
@@ -58,7 +59,9 @@ class Qwen2VLTextEngine:
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             # n_slots sequences of max_model_len tokens each (batched decode); n_slots = 1 is the single-request engine
-            _hip.check(self._L.td_qwen2_create_slots(ctypes.byref(cc), max_model_len, int(n_slots), ctypes.byref(h)))
+            # prefill_rows: activation-workspace rows = the capacity (sum of padded prompt lengths) of one batched prefill
+            self.prefill_rows = max(int(prefill_rows or 0), max_model_len)
+            _hip.check(self._L.td_qwen2_create_ex(ctypes.byref(cc), max_model_len, int(n_slots), self.prefill_rows, ctypes.byref(h)))
         self._h = h
         self.n_slots, self.slot_len = int(n_slots), max_model_len
         self.max_model_len = max_model_len
@@ -251,17 +254,36 @@ class Qwen2VLTextEngine:
         if B > min(self.MAX_BATCH, getattr(self, "n_slots", 1)):
             raise _hip.ThinkDiffHipError(f"generate_batch: {B} requests exceed min({self.MAX_BATCH}, n_slots={getattr(self, 'n_slots', 1)}); call set_slots first")
         res = [{"prompt_hidden_states": None, "hidden_states": [], "token_ids": []} for _ in range(B)]
-        cache_len, next_pos, rows = [], [], []
-        for b, r in enumerate(requests):
-            ids = list(r["prompt_token_ids"])
-            pos = self.text_position_ids(len(ids)) if r.get("position_ids") is None else r["position_ids"]
-            emb = r.get("inputs_embeds")
-            hid, lg = self.forward(pos, torch.tensor(ids, dtype=torch.int32) if emb is None else None, emb, 0, True, True, slot=b)
-            res[b]["prompt_hidden_states"] = hid
-            cache_len.append(len(ids))
-            next_pos.append(int(pos.max()) + 1)
-            rows.append(lg)
-        logits = torch.stack(rows)                  # [B, vocab], row i belongs to the sequence in slot i
+        cache_len = [len(r["prompt_token_ids"]) for r in requests]
+        poss = [self.text_position_ids(n) if r.get("position_ids") is None else r["position_ids"] for r, n in zip(requests, cache_len)]
+        next_pos = [int(p.max()) + 1 for p in poss]
+        L = (max(cache_len) + 7) // 8 * 8
+        if B > 1 and L <= self.slot_len and B * L <= self.prefill_rows:
+            # one pass over the weights for all prompts: right-padded to L rows each (causal attention keeps the padding inert)
+            D = self.config.hidden_size
+            emb = torch.zeros(B * L, D, dtype=torch.bfloat16, device=self.device)
+            pos = torch.zeros(3, B * L, dtype=torch.int32)
+            for b, (r, n, p) in enumerate(zip(requests, cache_len, poss)):
+                e = r.get("inputs_embeds")
+                emb[b * L:b * L + n] = self.embed_tokens(r["prompt_token_ids"]) if e is None else e.to(self.device, torch.bfloat16)
+                pos[:, b * L:b * L + n] = p.to(torch.int32)
+                pos[:, b * L + n:(b + 1) * L] = next_pos[b] + torch.arange(L - n, dtype=torch.int32)
+            pos = pos.to(self.device).contiguous()
+            hid = torch.empty(B * L, D, dtype=torch.bfloat16, device=self.device)
+            logits = torch.empty(B, self.config.vocab_size, dtype=torch.bfloat16, device=self.device)
+            lens = (ctypes.c_int * B)(*cache_len)
+            _hip.check(self._L.td_qwen2_prefill_batch(self._h, B, L, None, _hip.ptr(emb), _hip.ptr(pos), ctypes.cast(lens, ctypes.c_void_p),
+                                                      _hip.ptr(hid), _hip.ptr(logits), _hip.stream_ptr()))
+            for b, n in enumerate(cache_len):
+                res[b]["prompt_hidden_states"] = hid[b * L:b * L + n]
+        else:
+            rows = []
+            for b, (r, p) in enumerate(zip(requests, poss)):
+                e = r.get("inputs_embeds")
+                hid, lg = self.forward(p, torch.tensor(list(r["prompt_token_ids"]), dtype=torch.int32) if e is None else None, e, 0, True, True, slot=b)
+                res[b]["prompt_hidden_states"] = hid
+                rows.append(lg)
+            logits = torch.stack(rows)              # [B, vocab], row i belongs to the sequence in slot i
         owner = list(range(B))                      # slot -> request index
         stops = set(sampling.stop_token_ids or [])
         step = 0
