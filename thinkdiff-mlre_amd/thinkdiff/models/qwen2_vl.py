@@ -416,7 +416,14 @@ class QwenChatFrontend:
         for i in need:
             im = out[i]["multi_modal_data"]["image"]
             per_req.append(list(im) if isinstance(im, (list, tuple)) else [im])
-        feats = self.image_processor(images=[im for ims in per_req for im in ims], return_tensors="pt")
+        flat = [im for ims in per_req for im in ims]
+        if len(flat) > 2:      # resize / normalise / patchify is CPU work per image: spread it over threads (PIL and numpy drop the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(8, len(flat))) as pool:
+                parts = list(pool.map(lambda im: self.image_processor(images=[im], return_tensors="pt"), flat))
+            feats = {"pixel_values": torch.cat([f["pixel_values"] for f in parts]), "image_grid_thw": torch.cat([f["image_grid_thw"] for f in parts])}
+        else:
+            feats = self.image_processor(images=flat, return_tensors="pt")
         grid = feats["image_grid_thw"].tolist()
         merged = self.visual(feats["pixel_values"], grid).pooler_output
         merge = self.visual.merge
