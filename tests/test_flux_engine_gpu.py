@@ -178,3 +178,50 @@ def test_full_width_full_sequence_block_pair(hip):
     # must be closer to the fp8 oracle than fp8 is to bf16, deviate from bf16 as much as the oracle says it should, and <= 5e-2
     d_hip, d_ref = _rel_rmse(out8, out16), _rel_rmse(ref8, ref16)
     assert e88 < 5e-2 and e88 < 0.75 * d_hip and abs(d_hip - d_ref) < 0.25 * d_ref
+
+
+def test_from_pretrained_local_diffusers_directory(hip, tmp_path):
+    """FluxPipelineRewritePrompt.from_pretrained on a local diffusers-layout directory (transformer/ with TWO safetensors
+    shards + config.json, vae/ with config.json + safetensors incl. encoder keys to be ignored): same outputs as loading the
+    state dicts directly; a missing tensor is reported."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import vae_ref as V
+    from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
+    from thinkdiff.models.flux_vae import AutoencoderKLConfig, AutoencoderKLDecoder
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1)
+    sd, m = _build(cfg, seed=5)
+    vcfg = V.tiny_config()
+    vsd = V.init_weights(vcfg, seed=2)
+    (tmp_path / "transformer").mkdir()
+    (tmp_path / "vae").mkdir()
+    keys = sorted(sd)
+    half = len(keys) // 2
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(tmp_path / "transformer" / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(tmp_path / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    (tmp_path / "transformer" / "config.json").write_text(json.dumps({
+        "_class_name": "FluxTransformer2DModel", "in_channels": cfg.in_channels, "num_layers": cfg.num_layers, "num_single_layers": cfg.num_single_layers,
+        "attention_head_dim": 128, "num_attention_heads": cfg.num_attention_heads, "joint_attention_dim": cfg.joint_attention_dim,
+        "pooled_projection_dim": cfg.pooled_projection_dim, "guidance_embeds": cfg.guidance_embeds, "axes_dims_rope": [16, 56, 56], "patch_size": 1}))
+    vfull = dict(vsd)
+    vfull["encoder.conv_in.weight"] = torch.zeros(8, 3, 3, 3).bfloat16()          # a full checkpoint also carries the encoder
+    save_file({k: v.contiguous() for k, v in vfull.items()}, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    (tmp_path / "vae" / "config.json").write_text(json.dumps({"_class_name": "AutoencoderKL", "block_out_channels": list(vcfg.block_out_channels),
+                                                                "latent_channels": 16, "scaling_factor": 0.3611, "shift_factor": 0.1159}))
+    pipe = FluxPipelineRewritePrompt.from_pretrained(str(tmp_path), max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+    assert pipe.text_encoder is None and pipe.vae is not None
+    lat, pe, pool = _inputs(cfg, 8, 8, 24, seed=1)
+    img_ids, txt_ids = R.latent_image_ids(8, 8), torch.zeros(24, 3)
+    t, g = torch.tensor([0.5]), torch.tensor([3.5])
+    a = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0]
+    b = pipe.transformer.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0]
+    vm = AutoencoderKLDecoder(AutoencoderKLConfig(block_out_channels=vcfg.block_out_channels), max_latent_size=(16, 16))
+    vm.load_state_dict(vsd)
+    packed = (torch.randn(16, 64) * 0.8).bfloat16().cuda()
+    va, vb = vm.decode_packed(packed, 8, 8, output_type="pt"), pipe.vae.decode_packed(packed, 8, 8, output_type="pt")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(va, vb)
+    os_remove = (tmp_path / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors")
+    os_remove.unlink()
+    with pytest.raises(KeyError):
+        FluxPipelineRewritePrompt.from_pretrained(str(tmp_path), max_img_tokens=256, max_txt_tokens=64, max_steps=4)
