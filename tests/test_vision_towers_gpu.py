@@ -163,3 +163,46 @@ def test_image_request_hidden_states_match_qwen2vl_model(hip):
     embeds, texts = m.get_embed([{"prompt_token_ids": prompt, "multi_modal_data": {"image": image}}], embedding_type="both",
                                 need_process=False, forced_output_ids=[[3, 4, 5]])
     assert embeds[0].shape == (len(ids) + 3, 4096) and texts == ["3 4 5"]
+
+
+def test_qwen2vl_checkpoint_directory_loaders(hip, tmp_path):
+    """A Hugging Face Qwen2-VL directory (config.json with vision_config, sharded safetensors holding `model.*`, `visual.*`,
+    `lm_head.*`) -> Qwen2VLTextEngine.load_pretrained + HipQwen2VisionTransformer.from_pretrained, both the older flat names
+    and the newer `model.language_model.* / model.visual.*` nesting; results equal the state-dict constructors."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import qwen2vl_ref as Q
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    from thinkdiff.models.vision_towers import HipQwen2VisionTransformer
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLVisionConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VisionTransformerPretrainedModel
+    torch.manual_seed(4)
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=3)
+    vcfg = Qwen2VLVisionConfig(depth=2, embed_dim=320, hidden_size=cfg.hidden, num_heads=4, mlp_ratio=2)
+    vsd = {k: v.bfloat16() for k, v in Qwen2VisionTransformerPretrainedModel(vcfg).state_dict().items()}
+    tc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
+                           num_key_value_heads=cfg.num_kv_heads, intermediate_size=cfg.intermediate, vocab_size=cfg.vocab)
+    ref_e = Qwen2VLTextEngine(tc, max_model_len=128)
+    ref_e.load_state_dict(sd)
+    ref_v = HipQwen2VisionTransformer(vsd, num_heads=4)
+    ids = torch.randint(0, cfg.vocab, (33,), dtype=torch.int32)
+    patches, grid = torch.randn(48, 1176), [[1, 6, 8]]
+    want_h = ref_e.forward(ref_e.text_position_ids(33), ids)[0].clone()
+    want_v = ref_v(patches, grid).pooler_output.clone()
+    for style in ("flat", "nested"):
+        root = tmp_path / style
+        root.mkdir()
+        tp, vp = ("model.", "visual.") if style == "flat" else ("model.language_model.", "model.visual.")
+        full = {(tp + k[len("model."):] if k.startswith("model.") else k): v.contiguous() for k, v in sd.items()}
+        full.update({vp + k: v.contiguous() for k, v in vsd.items()})
+        keys = sorted(full)
+        save_file({k: full[k] for k in keys[::2]}, str(root / "model-00001-of-00002.safetensors"))
+        save_file({k: full[k] for k in keys[1::2]}, str(root / "model-00002-of-00002.safetensors"))
+        (root / "config.json").write_text(json.dumps({"model_type": "qwen2_vl", "vision_config": {"num_heads": 4, "spatial_merge_size": 2, "hidden_act": "quick_gelu"}}))
+        e = Qwen2VLTextEngine(tc, max_model_len=128).load_pretrained(str(root))
+        v = HipQwen2VisionTransformer.from_pretrained(str(root))
+        got_h = e.forward(e.text_position_ids(33), ids)[0]
+        got_v = v(patches, grid).pooler_output
+        torch.cuda.synchronize()
+        assert torch.equal(got_h, want_h) and torch.equal(got_v, want_v), style
