@@ -206,3 +206,39 @@ def test_qwen2vl_checkpoint_directory_loaders(hip, tmp_path):
         got_v = v(patches, grid).pooler_output
         torch.cuda.synchronize()
         assert torch.equal(got_h, want_h) and torch.equal(got_v, want_v), style
+
+
+def test_blip2_vision_on_disk_bias_names(hip, tmp_path):
+    """BLIP-2 checkpoints store the attention bias as `q_bias` / `v_bias` (k has none) under `vision_model.`; the in-memory
+    module fuses them into `qkv.bias`.  Both spellings, and HipBlip2VisionModel.from_pretrained on a directory, agree."""
+    import json
+    from safetensors.torch import save_file
+    from transformers import Blip2VisionConfig, Blip2VisionModel
+    from thinkdiff.models.vision_towers import HipBlip2VisionModel
+    torch.manual_seed(7)
+    cfg = Blip2VisionConfig(hidden_size=704, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8, image_size=112, patch_size=14, qkv_bias=True)
+    ref = Blip2VisionModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "qkv.bias" in n:
+                p.normal_(0, 0.05)
+                p[704:1408] = 0          # k carries no bias in the checkpoints
+            elif p.dim() > 1 and "embedding" not in n:
+                p.normal_(0, 0.04)
+    sd = {k: v.bfloat16() for k, v in ref.state_dict().items()}
+    disk = {}
+    for k, v in sd.items():
+        if k.endswith("self_attn.qkv.bias"):
+            disk["vision_model." + k.replace("qkv.bias", "q_bias")] = v[:704].clone()
+            disk["vision_model." + k.replace("qkv.bias", "v_bias")] = v[1408:].clone()
+        else:
+            disk["vision_model." + k] = v.contiguous()
+    disk["language_projection.weight"] = torch.zeros(8, 8).bfloat16()      # other parts of a BLIP-2 checkpoint are ignored
+    save_file(disk, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps({"vision_config": {"num_attention_heads": 8, "patch_size": 14, "layer_norm_eps": cfg.layer_norm_eps}}))
+    pix = torch.randn(1, 3, 112, 112)
+    a = HipBlip2VisionModel(sd, num_heads=8, eps=cfg.layer_norm_eps)(pix)[0]
+    b = HipBlip2VisionModel(disk, num_heads=8, eps=cfg.layer_norm_eps)(pix)[0]
+    c = HipBlip2VisionModel.from_pretrained(str(tmp_path))(pix)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
