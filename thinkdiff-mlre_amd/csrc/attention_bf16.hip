@@ -542,6 +542,9 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_ARG(((long long)(p.Sq + 256) * p.ldq) * 2 < (1ll << 32) && ((long long)(p.Skv + 64) * p.ldkv) * 2 < (1ll << 32),
                "td_attention: per-batch operand exceeds the 4 GiB buffer-descriptor range");
   TD_CHECK_ARG(((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0, "td_attention: pointers must be 16-byte aligned");
+  // one query token per sequence against its KV cache: the dedicated decode kernel (keys split over lanes, GQA group shares K/V)
+  if (p.Sq == 1 && p.causal && !p.bias && p.variant == 0 && (p.kv_lens || p.causal_offset == p.Skv - 1))
+    return td_attn_decode_launch(p, stream);
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
   // variant 0 (shipped): lean instruction stream (resident LDS addresses, prefetched fragments);

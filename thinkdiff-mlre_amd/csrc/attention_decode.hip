@@ -1,0 +1,123 @@
+// KV-cached decode attention (one query token per sequence) for gfx950.
+//
+// The prefill kernel (attention_bf16.hip) tiles 256 query rows per workgroup; with Sq = 1 it wastes 255 of them and walks the
+// cache one 64-key tile at a time in a single workgroup per head (13 us for 300 keys).  Here a workgroup owns one
+// (sequence, q head): its 4 waves split the keys 16 at a time -- a key row is read once by 16 lanes (16 B each, the whole
+// 256-B row coalesced) -- every 16-lane key slot keeps its own
+// online-softmax state and output slice in registers, and the 16 slots are merged at the end (shuffles inside a wave, LDS
+// across waves).  fp32 scores / softmax / accumulation; q.k through v_dot2c_f32_bf16.
+// Semantics = td_attn_launch with Sq = 1, causal, kv_lens (keys [0, kv_lens[b]) of sequence b are visible).
+#include "td_common.h"
+#include "td_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ float dot8q(const u32x4_t& a, const u32x4_t& b) {
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned ua = a[q], ub = b[q];   // copy out first: bit_cast on a vector-element lvalue reads element 0 (hipcc 7.2)
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ua), __builtin_bit_cast(bf16x2_t, ub), acc, false);
+  }
+  return acc;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams p) {
+  __shared__ float sm_m[4][G], sm_l[4][G];
+  __shared__ float sm_o[4][G][128];
+  // one workgroup per (q-head group of G, sequence); G = 1 launches one per q head: K/V of a kv head are then read by each of
+  // its q heads (from L2), which is cheap next to the parallelism it buys at small batch
+  const int qg = blockIdx.x, b = blockIdx.y;
+  const int kvh = (qg * G) / p.q_per_kv;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = lane & 15;                       // 16-B chunk of the 256-B head row
+  const int slot = wid * 4 + (lane >> 4);        // key slot 0..15
+  const int len = p.kv_lens ? p.kv_lens[b] : p.Skv;
+  const bf16_t* Kb = p.K + (size_t)b * p.kv_bstride + (size_t)kvh * 128 + 8 * j;
+  const bf16_t* Vb = p.V + (size_t)b * p.kv_bstride + (size_t)kvh * 128 + 8 * j;
+  const bf16_t* Qb = p.Q + (size_t)b * p.q_bstride + (size_t)qg * G * 128 + 8 * j;
+  u32x4_t q[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) q[g] = *(const u32x4_t*)(Qb + (size_t)g * 128);
+  float m[G], l[G], o[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[g][i] = 0.f;
+  }
+  const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
+  for (int key = slot; key < len; key += 16) {
+    const u32x4_t kk = *(const u32x4_t*)(Kb + (size_t)key * p.ldkv);
+    const u32x4_t vv = *(const u32x4_t*)(Vb + (size_t)key * p.ldkv);
+    float vf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { vf[2 * i] = bf_lo(vv[i]); vf[2 * i + 1] = bf_hi(vv[i]); }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float s = dot8q(kk, q[g]);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+      s *= sc;
+      const float mn = fmaxf(m[g], s);
+      const float corr = __builtin_amdgcn_exp2f(m[g] - mn), pe = __builtin_amdgcn_exp2f(s - mn);
+      m[g] = mn;
+      l[g] = l[g] * corr + pe;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[g][i] = o[g][i] * corr + pe * vf[i];
+    }
+  }
+  // merge the 4 key slots of this wave (lanes 16 / 32 apart hold the same d-chunk), then the 4 waves through LDS
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+      const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(l[g], off, 64);
+      const float mn = fmaxf(m[g], mo);
+      const float ca = m[g] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[g] - mn);
+      const float cb = mo == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mo - mn);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[g][i] = o[g][i] * ca + __shfl_xor(o[g][i], off, 64) * cb;
+      l[g] = l[g] * ca + lo * cb;
+      m[g] = mn;
+    }
+    if (lane < 16) {
+      if (lane == 0) { sm_m[wid][g] = m[g]; sm_l[wid][g] = l[g]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sm_o[wid][g][8 * j + i] = o[g][i];
+    }
+  }
+  __syncthreads();
+  // 256 threads: thread t writes output elements (g, d) for t = g' * 128 + d over ceil(G*128/256) passes
+  bf16_t* Ob = p.O + (size_t)b * p.o_bstride + (size_t)qg * G * 128;
+  for (int e = tid; e < G * 128; e += 256) {
+    const int g = e >> 7, d = e & 127;
+    float mn = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sm_m[w][g]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float c = sm_m[w][g] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sm_m[w][g] - mn);
+      num += sm_o[w][g][d] * c;
+      den += sm_l[w][g] * c;
+    }
+    Ob[e] = f2bf(den > 0.f ? num / den : 0.f);
+  }
+}
+
+}  // namespace
+
+int td_attn_decode_launch(const TdAttnParams& p, hipStream_t stream) {
+  TD_CHECK_ARG(p.Sq == 1 && p.head_dim == 128 && p.Hq % p.Hkv == 0, "td_attn_decode: needs Sq = 1, head_dim 128");
+  TdAttnParams q = p;
+  q.q_per_kv = p.Hq / p.Hkv;
+  TD_CHECK_ARG(p.ldkv % 8 == 0 && ((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0 && p.q_bstride % 8 == 0 && p.kv_bstride % 8 == 0,
+               "td_attn_decode: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(td_attn_decode_kernel<1>, dim3(p.Hq, p.batch), dim3(256), 0, stream, q);
+  TD_CHECK_LAUNCH();
+  return 0;
+}

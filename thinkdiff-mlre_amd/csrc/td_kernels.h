@@ -62,6 +62,8 @@ struct TdAttnParams {
 };
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);
+// Sq = 1 (KV-cached decode) form, csrc/attention_decode.hip; td_attn_launch routes to it
+int td_attn_decode_launch(const TdAttnParams& p, hipStream_t stream);
 
 struct TdNormParams {
   const bf16_t* x = nullptr; int ldx = 0;
