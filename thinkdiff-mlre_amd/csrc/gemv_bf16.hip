@@ -46,7 +46,11 @@ __global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParam
   const int nchunk = p.K >> 3;
   const u32x4_t* wp[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) wp[r] = (const u32x4_t*)(p.W + (size_t)min(n0 + r, p.N - 1) * p.K);
+  for (int r = 0; r < R; ++r) {
+    // gated mode: rows 0,1 = gate rows 2b, 2b+1; rows 2,3 = the matching up rows (glu_I further down the matrix)
+    const int row = p.glu_I ? (blockIdx.x * 2 + (r & 1) + (r >> 1) * p.glu_I) : min(n0 + r, p.N - 1);
+    wp[r] = (const u32x4_t*)(p.W + (size_t)row * p.K);
+  }
   const u32x4_t* xp[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) xp[m] = (const u32x4_t*)(p.A + (size_t)min(m, p.M - 1) * p.lda);
@@ -92,6 +96,16 @@ __global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParam
       if (lane == 0) red[wid][r][m] = v;
     }
   __syncthreads();
+  if (p.glu_I) {
+    if (tid >= 2 * MR) return;
+    const int i = tid / MR, m = tid % MR;
+    if (m >= p.M) return;
+    float gsum = 0.f, usum = 0.f;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) { gsum += red[w][i][m]; usum += red[w][i + 2][m]; }
+    p.C[(size_t)m * p.ldc + blockIdx.x * 2 + i] = f2bf(rbf(silu_f(rbf(gsum))) * rbf(usum));
+    return;
+  }
   if (tid >= R * MR) return;
   const int r = tid / MR, m = tid % MR;
   const int n = n0 + r;
@@ -125,7 +139,9 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const bf16_t* wrow = p.W + (size_t)min(n0 + r, p.N - 1) * p.K + 8 * g;
+  // gated mode: rows 0-7 = gate rows 8b..8b+7, rows 8-15 = the matching up rows
+  const int wr_ = p.glu_I ? (blockIdx.x * 8 + (r & 7) + (r >> 3) * p.glu_I) : min(n0 + r, p.N - 1);
+  const bf16_t* wrow = p.W + (size_t)wr_ * p.K + 8 * g;
   const bf16_t* xrow = p.A + (size_t)min(r, p.M - 1) * p.lda + 8 * g;
   const int nk = p.K >> 6;                      // 64-element steps
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -161,6 +177,17 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
   for (int w = 0; w < MW; ++w)
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += red[w][lane][i];
+  if (p.glu_I) {   // lanes g = 0,1 hold gate rows 4g+i, their partners 32 lanes up the matching up rows
+    float u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = __shfl(v[i], (lane + 32) & 63, 64);
+    if (g < 2 && r < p.M) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = rbf(silu_f(rbf(v[i]))) * rbf(u[i]);
+      *(u32x2_t*)(p.C + (size_t)r * p.ldc + blockIdx.x * 8 + 4 * g) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    }
+    return;
+  }
   // C layout of the MFMA: column (lane & 15) = activation row m, rows 4 (lane >> 4) + i = weight rows n
   const int m = r, n = n0 + 4 * g;
   if (m >= p.M || n >= p.N) return;
@@ -187,6 +214,18 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
 int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M >= 1 && p.M <= 16 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 16, N %% 4 == 0, K %% 8 == 0");
   TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W) % 16 == 0, "td_gemv: operands must be 16-byte aligned");
+  if (p.glu_I) {
+    TD_CHECK_ARG(p.N == p.glu_I && p.glu_I % 8 == 0 && !p.bias && !p.gate && !p.res && !p.C2 && p.act == TD_ACT_NONE && p.ldc % 4 == 0,
+                 "td_gemv(glu): N must equal glu_I (multiple of 8), no bias / gate / residual / split");
+    if (p.M > 4 && p.K % 64 == 0) hipLaunchKernelGGL(td_gemv_mfma_kernel, dim3(p.glu_I / 8), dim3(MW * 64), 0, stream, p);
+    else if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
+    else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
+    else if (p.M <= 4) hipLaunchKernelGGL(td_gemv_bf16_kernel<4>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
+    else if (p.M <= 8) hipLaunchKernelGGL(td_gemv_bf16_kernel<8>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(td_gemv_bf16_kernel<16>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
+    TD_CHECK_LAUNCH();
+    return 0;
+  }
   if (p.M > 4 && p.K % 64 == 0 && p.N % 16 == 0 && p.ldc % 4 == 0 && (!p.C2 || (p.ldc2 % 4 == 0 && p.n_split % 4 == 0)) && (!p.res || p.ldr % 1 == 0)) {
     hipLaunchKernelGGL(td_gemv_mfma_kernel, dim3(p.N / 16), dim3(MW * 64), 0, stream, p);
     TD_CHECK_LAUNCH();

@@ -83,6 +83,38 @@ __global__ void td_kv_rows_to_slots_kernel(const bf16_t* src, bf16_t* dst_base, 
   if (c < W) *(u32x4_t*)(dst_base + ((size_t)b * slot_len + t) * W + c) = *(const u32x4_t*)(src + (size_t)row * W + c);
 }
 
+// Decode step, one launch for: M-RoPE on the new q rows (in place), M-RoPE on the new k rows, k|v rows -> their sequences' cache
+// rows.  Rotation = rotate_half with every op rounding to bf16 (td_qk_norm_rope_kernel rotate_half == 2: q*cos, rot*sin, sum).
+__global__ __launch_bounds__(256) void td_decode_rope_scatter_kernel(bf16_t* q, const bf16_t* kv, bf16_t* cache, const int* row_off,
+                                                                     const float* cosT, const float* sinT, int Hq, int Hkv) {
+  const int b = blockIdx.x;
+  const int l16 = threadIdx.x & 15, unit0 = threadIdx.x >> 4;
+  const int QW = Hq * 128, KVW = 2 * Hkv * 128;
+  float cs[8], sn[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { cs[i] = cosT[(size_t)b * 128 + l16 * 8 + i]; sn[i] = sinT[(size_t)b * 128 + l16 * 8 + i]; }
+  bf16_t* dst = cache + (size_t)row_off[b];
+  for (int u = unit0; u < Hq + 2 * Hkv; u += 16) {
+    const bool is_q = u < Hq, is_v = u >= Hq + Hkv;
+    const bf16_t* src = is_q ? q + (size_t)b * QW + u * 128 + l16 * 8 : kv + (size_t)b * KVW + (u - Hq) * 128 + l16 * 8;
+    u32x4_t raw = *(const u32x4_t*)src;
+    if (!is_v) {
+      float x[8], y[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[2 * i] = bf_lo(raw[i]); x[2 * i + 1] = bf_hi(raw[i]); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float other = __shfl_xor(x[i], 8, 16);
+        const float rot = (l16 < 8) ? -other : other;
+        y[i] = rbf(x[i] * cs[i]) + rbf(rot * sn[i]);
+      }
+      raw = u32x4_t{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
+    }
+    bf16_t* out = is_q ? q + (size_t)b * QW + u * 128 + l16 * 8 : dst + (u - Hq) * 128 + l16 * 8;
+    *(u32x4_t*)out = raw;
+  }
+}
+
 #define TDQ_TRY(expr)         \
   do {                        \
     int _rc = (expr);         \
@@ -368,11 +400,6 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
   TDQ_TRY(td_mrope_table_launch(position_ids, B, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
   TdNormParams np;
   np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = B; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
-  TdQkRopeParams rq;
-  rq.qkv = f->q; rq.ld = QW; rq.rows = B; rq.Hq = Hq; rq.Hk = 0; rq.q_col = 0; rq.k_col = 0;
-  rq.cos = f->cosT; rq.sin = f->sinT; rq.rotate_half = 2;
-  TdQkRopeParams rk = rq;
-  rk.qkv = f->kvtmp; rk.ld = KVW; rk.Hq = Hkv;
   for (int i = 0; i < f->cfg.num_layers; ++i) {
     const QLayer& l = f->layers[i];
     np.w = l.ln1_w;
@@ -383,9 +410,7 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
       g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
       TDQ_TRY(td_gemm_launch(g, s));
     }
-    TDQ_TRY(td_qk_norm_rope_launch(rq, s));
-    TDQ_TRY(td_qk_norm_rope_launch(rk, s));
-    hipLaunchKernelGGL(td_scatter_rows_kernel, dim3((KVW / 8 + 255) / 256, B), dim3(256), 0, s, f->kvtmp, l.kv, row_off, KVW);
+    hipLaunchKernelGGL(td_decode_rope_scatter_kernel, dim3(B), dim3(256), 0, s, f->q, f->kvtmp, l.kv, row_off, f->cosT, f->sinT, Hq, Hkv);
     TdAttnParams ap;
     ap.Q = f->q; ap.ldq = QW; ap.q_bstride = QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW;
     ap.kv_bstride = (long long)f->slot_len * KVW; ap.O = f->attn; ap.ldo = QW; ap.o_bstride = QW;
@@ -401,9 +426,8 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
     TDQ_TRY(td_norm_rows_launch(np, s));
     {
       TdGemmParams g;
-      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = B; g.N = 2 * I; g.K = D;
+      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->act; g.ldc = I; g.M = B; g.N = I; g.K = D; g.glu_I = I;   // gate | up, SiLU and product in one pass
       TDQ_TRY(td_gemm_launch(g, s));
-      TDQ_TRY(td_silu_mul_launch(f->gu, f->act, B, I, s));
       TdGemmParams d;
       d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = B; d.N = D; d.K = I;
       TDQ_TRY(td_gemm_launch(d, s));

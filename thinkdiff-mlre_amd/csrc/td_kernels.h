@@ -28,6 +28,9 @@ struct TdGemmParams {
   // (k = tap*Cin + c, tap = ky*3+kx), M = conv_H*conv_W output pixels; conv_up = 1 fuses a nearest 2x upsample
   int conv_H = 0, conv_W = 0, conv_Cin = 0, conv_up = 0;
   // fp8 operands (fp8 = 1): A and W hold OCP e4m3 bytes (lda, K in elements = bytes); y = acc * a_scale[m] * w_scale[n]
+  // gated MLP in one pass (skinny-M kernels only, glu_I > 0): W = [gate rows | up rows] (2 * glu_I x K), N = glu_I outputs,
+  // C[m, n] = bf16(bf16(silu(bf16(x.gate_n))) * bf16(x.up_n)) -- Linear, SiLU and the product each round, as the separate kernels do
+  int glu_I = 0;
   int fp8 = 0;
   const float* a_scale = nullptr; const float* w_scale = nullptr;        // [M], [N]
   const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch

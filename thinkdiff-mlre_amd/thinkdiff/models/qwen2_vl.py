@@ -232,8 +232,9 @@ class Qwen2VLTextEngine:
             else:
                 nxt = self._sample(logits, sampling, generator)
             out_ids.append(nxt)
-            p1 = torch.full((3, 1), next_pos + step, dtype=torch.int32)
-            h1, logits = self.forward(p1, torch.tensor([nxt], dtype=torch.int32), None, n_p + step, True, True)
+            # one token against the cache: the decode step (fused rope + cache write, decode attention, gated-MLP weight stream)
+            h1, lg = self.decode_batch([nxt], [[next_pos + step]] * 3, [n_p + step])
+            logits = lg[0]
             out_hidden.append(h1)
             done_eos = (not sampling.ignore_eos) and eos_token_id is not None and nxt == eos_token_id
             if forced_output_ids is None and step + 1 >= sampling.min_tokens and (done_eos or nxt in stops):
