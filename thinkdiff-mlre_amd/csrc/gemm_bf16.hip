@@ -564,7 +564,8 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_ARG(p.conv_Cin % 64 == 0 && p.K == 9 * p.conv_Cin && p.M == p.conv_H * p.conv_W && p.g_M == 0 && !p.C2,
                  "td_gemm(conv): need Cin %% 64 == 0, K == 9 Cin, M == H W (got Cin=%d K=%d M=%d H=%d W=%d)", p.conv_Cin, p.K, p.M, p.conv_H, p.conv_W);
     TD_CHECK_ARG(p.conv_up == 0 || (p.conv_H % 2 == 0 && p.conv_W % 2 == 0), "td_gemm(conv): upsampled output dims must be even");
-    return p.N <= 64 ? launch_cfg<8, 1, 2, true>(p, stream) : launch_cfg<8, 4, 2, true>(p, stream);
+    // output-channel tile: 64, 128 (the 128-channel 1024^2 / 512^2 layers of the VAE: a 256-wide tile would be half empty) or 256
+    return p.N <= 64 ? launch_cfg<8, 1, 2, true>(p, stream) : p.N <= 128 ? launch_cfg<8, 2, 2, true>(p, stream) : launch_cfg<8, 4, 2, true>(p, stream);
   }
   // M <= 16 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode of up to 16 sequences, embedders, lm_head)
   if (p.glu_I) {
