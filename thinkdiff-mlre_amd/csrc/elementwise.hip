@@ -630,9 +630,43 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x,
   }
 }
 
+// the same with the row held in registers between the amax pass and the conversion (K = NCH * 512 <= 16384): one read of x
+template <int NCH>
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * ldx + lane * 8;
+  u32x4_t raw[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) raw[c] = *(const u32x4_t*)(xr + c * 512);
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(raw[c][i])), fabsf(bf_hi(raw[c][i]))));
+  amax = wave_max(amax);
+  const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / s;
+  if (lane == 0) scale[row] = s;
+  uint8_t* qr = q + (size_t)row * ldq + lane * 8;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    float v[8];
+    unpack8(raw[c], v);
+    *(u32x2_t*)(qr + c * 512) = pack8_fp8(v, inv);
+  }
+}
+
 int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream) {
   TD_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_fp8: bad arguments");
-  hipLaunchKernelGGL(td_quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, q, ldq, scale, rows, K);
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (K % 512 == 0 ? K / 512 : 0) {
+#define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows); break;
+    TD_CASE(1) TD_CASE(2) TD_CASE(4) TD_CASE(6) TD_CASE(8) TD_CASE(24) TD_CASE(30)
+#undef TD_CASE
+    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K);
+  }
   TD_CHECK_LAUNCH();
   return 0;
 }
