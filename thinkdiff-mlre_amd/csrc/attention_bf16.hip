@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     // before its consumer and expose the LDS latency 16 times per tile)
     f32x16_t st[2];
     {
-      constexpr int KPF = 4;
+      constexpr int KPF = 2;   // depth re-measured in-process at S = 4289: 2 / 2 beats 4 / 3 and 6 / 5 by 2 % (1 / 1 ties)
       auto kread = [&](int e) {   // e = kb * 8 + ks
         return *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e & 7] + (e >> 3) * 32 * 256);
       };
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 
     // ---- O^T += V^T . P^T ------------------------------------------------------------------------
     {
-      constexpr int VPF = 3;   // V^T fragments in flight ahead of their MFMA (2 transposed reads each)
+      constexpr int VPF = 2;   // V^T fragments in flight ahead of their MFMA (2 transposed reads each)
       auto vread = [&](int e, int jj) {   // e = (kb * 2 + s) * 4 + db
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(uintptr_t)(va[jj][e & 3] + (e >> 2) * 16 * 256));
       };
