@@ -153,6 +153,21 @@ def bench_batch3():
     print(f"per step (3 images): separate {tot1:.1f} ms, batched {tot3:.1f} ms  -> x{tot1/tot3:.3f}; per image per 28 steps {tot1*28/3:.0f} vs {tot3*28/3:.0f} ms")
 
 
+def bench_attn1():
+    """Joint attention at the FLUX shape, cold inputs (pool cycling)."""
+    S, H = 4289, 24
+    W = H * 128
+    pool = [torch.randn(1, S, 3 * W, device="cuda").bfloat16() for _ in range(6)]
+    o = torch.empty(1, S, W, device="cuda", dtype=torch.bfloat16)
+    st = {"i": 0}
+    def f():
+        st["i"] = (st["i"] + 1) % len(pool)
+        q = pool[st["i"]]
+        _hip.attention(q[:, :, :W], q[:, :, W:2 * W], q[:, :, 2 * W:], o, H, H)
+    ms = min(timeit(f, iters=20, warmup=3) for _ in range(6))
+    print(f"attention S={S} H={H}: {ms*1e3:6.1f} us  {4.0*S*S*H*128/ms/1e9:6.0f} TF/s")
+
+
 def bench_gemmcold():
     """Tile/pipeline variants with L3-warm weights (one W re-used) vs cold weights (cycling a 1 GB pool, as in
     the real denoise loop where every layer's weights stream from HBM).  Interleaved rounds, best-of."""
