@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     }
   }
 
-  // ---- resident per-lane LDS byte addresses (slot 0; "^= TILE_BYTES" flips the slot) ----------------
+  // ---- resident per-lane LDS byte addresses of slot 0 (the other slot is an immediate offset in the tile body) ----
   const unsigned lds0 = (unsigned)(uintptr_t)(TD_LDS char*)smem;   // LDS byte address of the tile area
   unsigned ka[8];      // K row read: row l31 (+32 kb as an immediate), chunk (2 ks + h5) ^ swz(row)
   {
