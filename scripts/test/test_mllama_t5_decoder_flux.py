@@ -27,6 +27,7 @@ import thinkdiff.models  # noqa: E402,F401  (registers the archs)
 from thinkdiff import tasks  # noqa: E402
 from thinkdiff.common.config import Config  # noqa: E402
 from thinkdiff.common.dist_utils import get_rank, init_distributed_mode  # noqa: E402
+from thinkdiff.runners import dp_inference as dp  # noqa: E402
 from thinkdiff.models import providers  # noqa: E402
 from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt  # noqa: E402
 from thinkdiff.models.flux_transformer import FluxTransformerConfig  # noqa: E402
@@ -73,16 +74,50 @@ class LvlmFluxDriver:
             return self.text.clip_pooled("", self.device)
         return self.pipe.encode_prompt(prompt="", prompt_2=None, prompt_embeds=torch.zeros(1, 1, 1))[1]
 
+    def _render(self, members, language_model_inputs, pooled, names, out_dir, gens=None):
+        """One pipeline call for requests with equal token counts (they advance together on the engine's contexts)."""
+        run = self.cfg.run_cfg
+        h, w = run.get("flux_height", 1024), run.get("flux_width", 1024)
+        steps = run.get("flux_num_inference_steps", 28)
+        written = []
+        with torch.no_grad():
+            lat = torch.cat([self.pipe.prepare_latents(1, h, w, generator=None if gens is None else gens[k])[0] for k in range(len(members))])
+            pe = torch.stack([language_model_inputs[i].to(torch.bfloat16) for i in members])
+            outs = self.pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled.expand(len(members), -1).contiguous(), num_images_per_prompt=1,
+                             height=h, width=w, num_inference_steps=steps, guidance_scale=run.get("guidance_scale", 3.5), latents=lat).images
+        for i, image in zip(members, outs):
+            path = f"{out_dir}/{names[i]}_output_embed_flux_0.png"
+            image.save(path, format="PNG", compress_level=1)
+            print(f"Saved image to {path}")
+            written.append(path)
+        return written
+
     def run(self):
         run = self.cfg.run_cfg
         out_dir = run["output_dir"]
         os.makedirs(out_dir, exist_ok=True)
         urls = list(run.get("img_urls", None) or DEFAULT_URLS)
         answers = list(run.get("answers", None) or DEFAULT_ANSWERS)
-        images = [[Image.open(u).convert("RGB")] for u in urls]
         names = [u.split("/")[-1].split(".")[0] for u in urls]
-        sample = {"images": images, "answers": answers}
         embedding_type = self.cfg.model_cfg.get("embedding_type", "output_embed")
+        pooled = self.pooled_empty_prompt().to(torch.bfloat16)
+        if run.get("shard_prompts", False):
+            # SURVEY.md 8(e): rank 0 broadcasts [(request index, seed)], every rank takes work[rank::world]; each request is
+            # sampled and rendered under its own seed (seed + index), so the images do not depend on the world size
+            work = dp.shard(dp.broadcast_work_list([(i, run.seed + i) for i in range(len(urls))] if get_rank() == 0 else None))
+            written = []
+            for i, seed in work:
+                setup_seeds(seed)
+                sample = {"images": [[Image.open(urls[i]).convert("RGB")]], "answers": [answers[i]]}
+                with torch.no_grad():
+                    lm_in, generated = self.model.get_embed(sample, embedding_type=embedding_type, max_new_tokens=128)
+                print(lm_in[0].shape, answers[i], generated[0], sep="\n")
+                gen = torch.Generator(device=self.pipe._execution_device).manual_seed(int(seed))
+                written += self._render([i], {i: lm_in[0]}, pooled, names, out_dir, gens=[gen])
+            every = dp.gather_results(written)
+            return every if every is not None else written
+        images = [[Image.open(u).convert("RGB")] for u in urls]
+        sample = {"images": images, "answers": answers}
         with torch.no_grad():
             language_model_inputs, generated = self.model.get_embed(sample, embedding_type=embedding_type, max_new_tokens=128)
         for i, text in enumerate(generated):
@@ -90,27 +125,14 @@ class LvlmFluxDriver:
             print(answers[i])
             print(text)
         print(urls)
-        pooled = self.pooled_empty_prompt().to(torch.bfloat16)
-        h, w = run.get("flux_height", 1024), run.get("flux_width", 1024)
-        steps = run.get("flux_num_inference_steps", 28)
         written = []
         G = self.pipe.images_in_flight
         for g0 in range(0, len(urls), G):            # requests with equal token counts advance together
-            idx = [i for i in range(g0, min(g0 + G, len(urls)))]
             groups = {}
-            for i in idx:
+            for i in range(g0, min(g0 + G, len(urls))):
                 groups.setdefault(language_model_inputs[i].shape[0], []).append(i)
             for members in groups.values():
-                with torch.no_grad():
-                    lat = torch.cat([self.pipe.prepare_latents(1, h, w)[0] for _ in members])
-                    pe = torch.stack([language_model_inputs[i].to(torch.bfloat16) for i in members])
-                    outs = self.pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled.expand(len(members), -1).contiguous(), num_images_per_prompt=1,
-                                     height=h, width=w, num_inference_steps=steps, guidance_scale=run.get("guidance_scale", 3.5), latents=lat).images
-                for i, image in zip(members, outs):
-                    path = f"{out_dir}/{names[i]}_output_embed_flux_0.png"
-                    image.save(path, format="PNG", compress_level=1)
-                    print(f"Saved image to {path}")
-                    written.append(path)
+                written += self._render(members, language_model_inputs, pooled, names, out_dir)
         return written
 
 

@@ -49,7 +49,7 @@ def test_driver_groups_images_in_flight_without_changing_them(hip, tmp_path):
         for G in (1, 3):
             out = tmp_path / f"out_{prec}_{G}"
             written = drv.main(base + [f"run.output_dir={out}", f"run.images_in_flight={G}", f"run.flux_precision={prec}"])
-            assert len(written) == 4 and os.path.basename(written[3]).startswith("img0_img1_apple")
+            assert len(written) == 4 and os.path.basename(written[3]) == "img0_img1_clip_t5_flux_apple_seed_42.png"   # reference ..._flux_text.py:254
             digests[prec, G] = [hashlib.sha256(open(w, "rb").read()).hexdigest() for w in written]
         assert digests[prec, 1] == digests[prec, 3]
     assert digests["bf16", 1] != digests["fp8", 1]
@@ -102,3 +102,66 @@ def test_precompute_job_end_to_end(hip, tmp_path):
     ie = torch.load(io.BytesIO(one[".model.norm.input_embed.pth"])) if isinstance(one[".model.norm.input_embed.pth"], bytes) else one[".model.norm.input_embed.pth"]
     assert oe.shape == (12, 512) and oe.dtype == torch.bfloat16 and ie.shape == (len(js["input_prompt_token_ids"]), 512)
     assert js["input_prompt_token_ids"].count(151655) > 1            # the image placeholder was expanded to the merged vision tokens
+
+
+def test_two_image_driver_entry_point(hip, tmp_path):
+    """BASELINE config 5's launcher (reference scripts/test/test_blip_vision_t5_decoder_flux.py): questions mode honours
+    use_image_name_as_output_name (:161-162); without it the name is {image}_clip_t5_flux_{name}_seed_{seed}.png (:164)."""
+    from scripts.test import test_blip_vision_t5_decoder_flux as drv
+    imgs = []
+    for k, col in enumerate([(200, 30, 40), (10, 20, 190)]):
+        p = tmp_path / f"pic{k}.jpg"
+        Image.new("RGB", (80, 64 + 8 * k), col).save(p)
+        imgs.append(str(p))
+    base = ["--cfg-path", os.path.join(HERE, "golden", "thinkdiff_clip_driver_keys.yaml"), "--options",
+            "run.synthetic=true", "run.synthetic_tiny=true", "run.flux_height=128", "run.flux_width=128", "run.flux_num_inference_steps=2",
+            f"run.img_urls=[[{imgs[0]},{imgs[1]}]]", "run.questions=['']", "run.questions_names=['null']", "run.prompt_json=",
+            "run.use_image_name_and_prompt_as_output_name=false", "model.ckpt="]
+    out = tmp_path / "o1"
+    written = drv.main(base + [f"run.output_dir={out}", "run.use_image_name_as_output_name=true"])
+    assert [os.path.basename(w) for w in written] == ["pic0_pic1.png"] and Image.open(written[0]).size == (128, 128)
+    out = tmp_path / "o2"
+    written = drv.main(base + [f"run.output_dir={out}"])
+    assert [os.path.basename(w) for w in written] == ["pic0_pic1_clip_t5_flux_null_seed_42.png"]
+    # sharded mode on one rank: same job, its own seed (seed + job index = 42) in the name
+    out = tmp_path / "o3"
+    written = drv.main(base + [f"run.output_dir={out}", "run.shard_prompts=true"])
+    assert [os.path.basename(w) for w in written] == ["pic0_pic1_clip_t5_flux_null_seed_42.png"]
+
+
+def test_lvlm_multi_image_drivers(hip, tmp_path):
+    """Reference scripts/test/test_mllama_t5_decoder_flux_multi_image.py and ..._multi_image_input.py in miniature: chat
+    request with two pictures (add_vision_id) -> get_embed(need_process=False) -> aligner -> FLUX 512^2; the input variant
+    conditions on [aligner tokens || T5(question)] and CLIP(question)."""
+    import torch
+    from scripts.test import test_mllama_t5_decoder_flux_multi_image as mi
+    from scripts.test import test_mllama_t5_decoder_flux_multi_image_input as mii
+    from thinkdiff.common.config import Config
+    imgs = []
+    for k, col in enumerate([(250, 250, 250), (20, 30, 220)]):
+        p = tmp_path / f"car{k}.jpg"
+        Image.new("RGB", (140, 112), col).save(p)
+        imgs.append(str(p))
+    common = ["--cfg-path", os.path.join(HERE, "golden", "thinkdiff_lvlm_driver_keys.yaml"), "--options",
+              "run.synthetic=true", "run.synthetic_tiny=true", "run.distributed=false", "model.ckpt=/ckpts/thinkdiff_lvlm.pth",
+              "model.vllm_config.max_model_len=1024", "model.vllm_config.max_tokens=16", "model.vllm_config.min_tokens=16",
+              "model.text_config={hidden_size: 512, num_hidden_layers: 2, num_attention_heads: 4, num_key_value_heads: 2, intermediate_size: 1024, vocab_size: 152064}"]
+    out = tmp_path / "mi"
+    written = mi.main(common + [f"run.output_dir={out}", f"run.image_paths=[{imgs[0]},{imgs[1]}]"])
+    assert [os.path.basename(w) for w in written] == ["car_white_blue_red_output_embed_edit_4_flux_0_thinkdiff_lvlm.pth.png"]   # reference :267
+    assert Image.open(written[0]).size == (512, 512)
+    # same seed, same request -> the re-seed before the FLUX call (:252) makes a second run reproduce the image bit for bit
+    out2 = tmp_path / "mi2"
+    again = mi.main(common + [f"run.output_dir={out2}", f"run.image_paths=[{imgs[0]},{imgs[1]}]"])
+    assert open(written[0], "rb").read() == open(again[0], "rb").read()
+
+    out = tmp_path / "mii"
+    argv = common + [f"run.output_dir={out}", f"run.image_paths=[{imgs[0]}]", "run.image_names=[LAIONEval4000_0]"]
+    d = mii.LvlmMultiImageInputFluxDriver(Config(mi.parse_args(argv)))
+    lm = torch.randn(16, 4096, device="cuda").bfloat16()
+    pe, pooled = d.condition(lm, d.QUESTION)
+    assert pe.shape == (1, 16 + 128, 4096) and pooled.shape == (1, 768)
+    assert torch.equal(pe[0, :16], lm) and torch.equal(pe[0, 16:], d.text.t5(d.QUESTION, 128, d.device)[0].to(torch.bfloat16))   # aligner first
+    assert torch.equal(pooled, d.text.clip_pooled(d.QUESTION, d.device).to(torch.bfloat16))                                     # CLIP(question)
+    written = d.run()
+    assert [os.path.basename(w) for w in written] == ["LAIONEval4000_0_output_embed_edit_4_flux_0_thinkdiff_lvlm.pth_seed_42.png"]   # reference :337

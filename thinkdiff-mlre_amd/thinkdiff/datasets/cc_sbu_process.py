@@ -7,14 +7,28 @@ from typing import Any, Dict, List, Optional, Sequence
 
 from .wds_io import ShardListDataset
 
-# The reference ships its own list of 16 brief-description instructions (cc_sbu_dataset_mllama_vllm_process_wids.py:
-# 13-33); any list can be supplied through `instructions=`.  These defaults are ours.
-DEFAULT_INSTRUCTIONS = [
+# The instruction table of the job, carried as data in the reference's order (cc_sbu_dataset_mllama_vllm_process_wids.py:
+# 11-27): `random.choice` under the same seed must pick the same instruction for the same sample, otherwise the generated
+# text and the hidden-state shards are a different dataset.  11 brief-description + 5 diffusion-prompt instructions.
+llava_brief_instructions = [
     "Describe the image concisely.",
-    "Give a brief description of the picture.",
-    "Summarize what the image shows in one or two sentences.",
-    "Write a short caption that captures the content of the photo.",
+    "Provide a brief description of the given image.",
+    "Offer a succinct explanation of the picture presented.",
+    "Summarize the visual content of the image.",
+    "Give a short and clear explanation of the subsequent image.",
+    "Share a concise interpretation of the image provided.",
+    "Present a compact description of the photo's key features.",
+    "Relay a brief, clear account of the picture shown.",
+    "Render a clear and concise summary of the photo.",
+    "Write a terse but informative summary of the picture.",
+    "Create a compact narrative representing the image presented.",
+    "Generate a prompt that can recreate the image in a 2D diffusion model.",
+    "Provide a descriptive prompt to reproduce the given image using a diffusion model.",
+    "Create a prompt suitable for a 2D diffusion model to generate the same image.",
+    "Summarize the visual details as a prompt for a 2D diffusion model.",
+    "Write a clear prompt to guide a 2D diffusion model in recreating the image.",
 ]
+DEFAULT_INSTRUCTIONS = llava_brief_instructions      # `instructions=` overrides the table (tests, other jobs)
 
 
 class CCSBUMllamaVllmProcessDatasetWids:

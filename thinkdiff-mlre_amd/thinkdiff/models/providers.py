@@ -102,17 +102,28 @@ class SyntheticQwenChat:
             self._ip = Qwen2VLImageProcessor(**self._ip_args)
         return self._ip
 
-    def apply_chat_template(self, conversations, tokenize=False, add_generation_prompt=True):
+    def apply_chat_template(self, conversations, tokenize=False, add_generation_prompt=True, add_vision_id=False):
+        """A list of conversations -> list of prompts; ONE conversation (a list of turns) -> one prompt, as the HF processor
+        does.  add_vision_id: the Qwen2-VL template's "Picture N: " label in front of every image (the reference's
+        multi-image drivers set it, scripts/test/test_mllama_t5_decoder_flux_multi_image.py:217-220)."""
+        single = bool(conversations) and isinstance(conversations[0], dict)
         out = []
-        for conv in conversations:
-            text = ""
+        for conv in ([conversations] if single else conversations):
+            text, n_img = "", 0
             for turn in conv:
                 body = turn["content"]
                 if not isinstance(body, str):
-                    body = "".join("<|vision_start|><|image_pad|><|vision_end|>" if part["type"] == "image" else part["text"] for part in body)
+                    parts = []
+                    for part in body:
+                        if part["type"] == "image":
+                            n_img += 1
+                            parts.append((f"Picture {n_img}: " if add_vision_id else "") + "<|vision_start|><|image_pad|><|vision_end|>")
+                        else:
+                            parts.append(part["text"])
+                    body = "".join(parts)
                 text += f"<|im_start|>{turn['role']}\n{body}<|im_end|>\n"
             out.append(text + ("<|im_start|>assistant\n" if add_generation_prompt else ""))
-        return out
+        return out[0] if single else out
 
     def encode(self, text, add_special_tokens=False):
         import re

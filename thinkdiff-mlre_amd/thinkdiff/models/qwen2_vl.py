@@ -361,6 +361,55 @@ class Qwen2VLTextEngine:
         return int(torch.multinomial(probs, 1, generator=generator))
 
 
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 4 * 28 * 28, max_pixels: int = 16384 * 28 * 28):
+    """[ext] qwen_vl_utils.smart_resize / transformers Qwen2-VL image processing: both sides to multiples of `factor`,
+    area inside [min_pixels, max_pixels], aspect ratio kept as closely as the grid allows."""
+    import math
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
+    h_bar = max(factor, round(height / factor) * factor)
+    w_bar = max(factor, round(width / factor) * factor)
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def process_vision_info(conversations):
+    """The image half of [ext] qwen_vl_utils.process_vision_info, which the reference's multi-image drivers call on their
+    chat messages (scripts/test/test_mllama_t5_decoder_flux_multi_image.py:223): every {"type": "image", "image": path | PIL,
+    ["min_pixels", "max_pixels" | "resized_height", "resized_width"]} part, in message order, opened as RGB and resized
+    so that both sides are multiples of 28 and the area lies inside the part's pixel budget (defaults 4*28*28 ..
+    16384*28*28).  Returns (images | None, None) -- videos are not part of the ThinkDiff path."""
+    from PIL import Image
+    convs = conversations if conversations and isinstance(conversations[0], (list, tuple)) else [conversations]
+    images = []
+    for conv in convs:
+        for turn in conv:
+            if isinstance(turn.get("content"), str):
+                continue
+            for part in turn["content"]:
+                if part.get("type") != "image" and "image" not in part:
+                    continue
+                im = part["image"]
+                if isinstance(im, str):
+                    im = Image.open(im[len("file://"):] if im.startswith("file://") else im)
+                im = im.convert("RGB")
+                if "resized_height" in part and "resized_width" in part:
+                    rh, rw = smart_resize(part["resized_height"], part["resized_width"], factor=28)
+                else:
+                    w, h = im.size
+                    rh, rw = smart_resize(h, w, factor=28, min_pixels=part.get("min_pixels", 4 * 28 * 28),
+                                          max_pixels=part.get("max_pixels", 16384 * 28 * 28))
+                images.append(im.resize((rw, rh)))
+    return (images or None), None
+
+
 SYSTEM_PROMPT = "You are a helpful assistant."   # reference mllama_vllm_t5_embed_decoder_2.py:1048, mllama_vllm_generate_1.py:551
 
 
