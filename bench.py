@@ -153,7 +153,7 @@ def main():
     def one_image(n=G):
         return pipe(prompt_embeds=prompt_embeds[:n], pooled_prompt_embeds=pooled[:n], num_images_per_prompt=1,
                     height=HEIGHT, width=WIDTH, num_inference_steps=NUM_STEPS, guidance_scale=GUIDANCE,
-                    latents=packed[:n].clone(), output_type="pil").images
+                    latents=packed[:n], output_type="pil").images
 
     def fence():
         torch.cuda.synchronize()

@@ -106,11 +106,13 @@ int td_qk_norm_rope_bf16(void* qkv, int64_t ld, int rows, int Hq, int Hk, int q_
 int td_flux_rope_table(const float* ids, int S, const int* axes_dims3, double theta, float* cos, float* sin, void* stream);
 /* Timesteps(256) sinusoid: t fp32 [n] (device) -> bf16 [n,256] = [cos | sin]. */
 int td_timestep_sincos(const float* t, int n, void* out, void* stream);
-/* FlowMatchEulerDiscreteScheduler.step on bf16 latents: x = bf16(float(x) + dt*float(v)). */
+/* FlowMatchEulerDiscreteScheduler.step on bf16 latents: x = bf16(float(x) + dt*float(v)), product and sum each rounded
+ * to fp32 as torch's `sample + dt * model_output` does (no fused multiply-add). */
 int td_euler_step_bf16(void* x, const void* v, float dt, int64_t n, void* stream);
 /* FluxPipeline._pack_latents (unpack=0: [C,H,W] -> [(H/2)(W/2),4C]) / _unpack_latents (unpack=1, with
- * out = in*mul + add, i.e. the z/scaling_factor + shift_factor that precedes vae.decode). */
-int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float mul, float add, void* stream);
+ * out = bf16(bf16(in / div) + add), i.e. the `latents / scaling_factor + shift_factor` on bf16 tensors that precedes
+ * vae.decode in [ext] pipeline_flux.py: quotient and sum each round to bf16; div = 1, add = 0 is a pure unpack). */
+int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float div, float add, void* stream);
 /* ThinkDiff-CLIP token pooling (blip_vision_t5_decoder.py:620-637): [1+G*G,C] -> [1+(G/2)^2,C]. */
 int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream);
 /* counter-based N(mean,std) fill (synthetic checkpoints for throughput runs). */
@@ -322,6 +324,14 @@ int td_qwen2_embed_tokens(td_qwen2* f, const int* token_ids, void* out, int n, v
 int td_embed_gather_bf16(const int* ids, const void* table, void* out, int n, int D, int vocab, void* stream);
 int td_silu_mul_bf16(const void* gate_up, void* out, int rows, int I, void* stream);
 int td_mrope_table(const int* pos3n, int n, const int* sections3, float theta, int round_bf16, float* cos, float* sin, void* stream);
+/* Temperature / top-p (nucleus) sampling, one token per row of bf16 logits [rows, ld], in ONE launch and without a sort:
+ *   p = softmax(logits / temperature); keep the most likely tokens while the mass in front of a token is < top_p; renormalise;
+ *   draw one token per row -> out_ids[rows] (device int32).  temperature <= 0: greedy (first index of the row maximum).
+ * The draw of row r is a pure function of (seed, offset, r): callers advance `offset` once per generated token.
+ * vocab % 8 == 0, ld % 8 == 0, rows <= 65535.  Replaces the sampler of vllm.SamplingParams(temperature, top_p) inside
+ * LLM.generate (thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:817-823, thinkdiff/models/mllama_vllm_generate_1.py:398-405). */
+int td_sample_top_p_bf16(const void* logits, int64_t ld, int rows, int vocab, float temperature, float top_p,
+                         uint64_t seed, uint64_t offset, int32_t* out_ids, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,22 @@
+"""torch.ops.thinkdiff_hip.* (SURVEY.md 8(b) custom-op layer): the namespace registers on CPU, carries the documented
+schemas, and has no host kernel to fall back to."""
+import pytest
+import torch
+
+
+def test_namespace_and_schemas():
+    import thinkdiff.ops as ops
+    assert ops.register() is ops.register()
+    for name in ops.SCHEMAS:
+        op = getattr(torch.ops.thinkdiff_hip, name)
+        assert str(op.default._schema).startswith(f"thinkdiff_hip::{name}(")
+    s = str(torch.ops.thinkdiff_hip.linear.default._schema)
+    assert "Tensor? bias" in s and "int act" in s and s.endswith("-> Tensor")
+    assert "Tensor(a!) x" in str(torch.ops.thinkdiff_hip.euler_step_.default._schema)
+
+
+def test_no_cpu_kernel():
+    import thinkdiff.ops  # noqa: F401
+    x, w = torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.thinkdiff_hip.linear(x, w, None, 0, None, None)

@@ -126,8 +126,8 @@ int td_timestep_sincos(const float* t, int n, void* out, void* stream) {
 int td_euler_step_bf16(void* x, const void* v, float dt, int64_t n, void* stream) {
   return td_euler_step_launch((bf16_t*)x, (const bf16_t*)v, dt, n, (hipStream_t)stream);
 }
-int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float mul, float add, void* stream) {
-  return td_flux_pack_launch((const bf16_t*)src, (bf16_t*)dst, C, H, W, unpack, mul, add, (hipStream_t)stream);
+int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float div, float add, void* stream) {
+  return td_flux_pack_launch((const bf16_t*)src, (bf16_t*)dst, C, H, W, unpack, div, add, (hipStream_t)stream);
 }
 int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream) {
   return td_cls_avgpool2_launch((const bf16_t*)x, (bf16_t*)y, G, C, (hipStream_t)stream);
@@ -235,6 +235,12 @@ int td_norm_rows_quant_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, flo
   if (p.scaleA && !p.scaleB) { p.scaleB = p.scaleA; p.shiftB = p.shiftA; }
   TD_CHECK_ARG(q && q_scale, "td_norm_rows_quant_fp8: null output");
   return td_norm_rows_launch(p, (hipStream_t)stream);
+}
+
+int td_sample_top_p_bf16(const void* logits, int64_t ld, int rows, int vocab, float temperature, float top_p,
+                         uint64_t seed, uint64_t offset, int32_t* out_ids, void* stream) {
+  TD_CHECK_ARG(logits && out_ids, "td_sample_top_p_bf16: null pointer");
+  return td_sample_top_p_launch((const bf16_t*)logits, (long long)ld, rows, vocab, temperature, top_p, seed, offset, out_ids, (hipStream_t)stream);
 }
 
 }  // extern "C"

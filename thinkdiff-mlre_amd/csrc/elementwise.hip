@@ -292,7 +292,7 @@ __global__ void td_euler_step_kernel(bf16_t* x, const bf16_t* v, float dt, int n
   unpack8(((const u32x4_t*)x)[idx], a);
   unpack8(((const u32x4_t*)v)[idx], b);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = a[i] + dt * b[i];
+  for (int i = 0; i < 8; ++i) a[i] = __fadd_rn(a[i], __fmul_rn(dt, b[i]));   // torch: sample + dt * model_output, two fp32 roundings (no fma)
   ((u32x4_t*)x)[idx] = pack8(a);
 }
 
@@ -307,7 +307,7 @@ int td_euler_step_launch(bf16_t* x, const bf16_t* v, float dt, long long n, hipS
 // FluxPipeline._pack_latents / _unpack_latents: [C,H,W] <-> [(H/2)(W/2), C*4], token (i,j) holds
 // x[c, 2i+di, 2j+dj] at column c*4 + di*2 + dj.  Unpack optionally applies z/scaling + shift (the
 // pre-VAE affine of FluxPipeline.__call__).  One thread per token row element pair.
-__global__ void td_flux_pack_kernel(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add) {
+__global__ void td_flux_pack_kernel(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float div, float add) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = C * H * W;
   if (idx >= total) return;
@@ -318,14 +318,15 @@ __global__ void td_flux_pack_kernel(const bf16_t* src, bf16_t* dst, int C, int H
   const int wj = W / 2;
   const int i = tok / wj, j = tok % wj;
   const size_t sp = ((size_t)c * H + (2 * i + di)) * W + (2 * j + dj);
-  if (unpack) dst[sp] = f2bf(bf2f(src[idx]) * mul + add);
+  if (unpack) dst[sp] = f2bf(__fadd_rn(rbf(__fdiv_rn(bf2f(src[idx]), div)), add));   // (z / scaling) + shift: two bf16 torch ops, each rounds
   else dst[idx] = src[sp];
 }
 
-int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add, hipStream_t stream) {
+int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float div, float add, hipStream_t stream) {
   TD_CHECK_ARG(C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "td_flux_pack: bad latent shape %dx%dx%d", C, H, W);
+  TD_CHECK_ARG(!unpack || div != 0.f, "td_flux_pack: scaling divisor must be non-zero");
   const int total = C * H * W;
-  hipLaunchKernelGGL(td_flux_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, src, dst, C, H, W, unpack, mul, add);
+  hipLaunchKernelGGL(td_flux_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, src, dst, C, H, W, unpack, div, add);
   TD_CHECK_LAUNCH();
   return 0;
 }

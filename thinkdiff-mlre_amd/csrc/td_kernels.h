@@ -102,7 +102,7 @@ int td_flux_rope_table_launch(const float* ids, int S, const int* axes, double t
 int td_timestep_sincos_launch(const float* t, int n, bf16_t* out, hipStream_t stream);
 int td_temb_combine_silu_launch(const bf16_t* te, const bf16_t* ge, const bf16_t* pe, int n, int D, bf16_t* temb, bf16_t* silu_out, hipStream_t stream);
 int td_euler_step_launch(bf16_t* x, const bf16_t* v, float dt, long long n, hipStream_t stream);
-int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float mul, float add, hipStream_t stream);
+int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float div, float add, hipStream_t stream);
 int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t stream);
 
 int td_embed_gather_launch(const int* ids, const bf16_t* table, bf16_t* out, int n, int D, int vocab, hipStream_t stream);
@@ -114,7 +114,7 @@ int td_groupnorm_nhwc_launch(const bf16_t* x, bf16_t* y, int P, int C, int G, fl
                              int silu, float* workspace, hipStream_t stream);
 int td_softmax_rows_launch(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t stream);
 int td_conv_pack_launch(const bf16_t* w, bf16_t* out, int Cout, int Cin, int Cout_pad, int Cin_pad, hipStream_t stream);
-int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float mul, float add, hipStream_t stream);
+int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float div, float add, hipStream_t stream);
 int td_image_finalize_launch(const bf16_t* x, int P, int Cpad, unsigned char* u8, bf16_t* chw, hipStream_t stream);
 extern "C" int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float mean, void* stream);
 
@@ -126,3 +126,7 @@ int td_rope_half_launch(bf16_t* x, int ldx, int S, int H, int head_stride, int h
 int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, float* cs, float* sn, hipStream_t stream);
 int td_patchify_launch(const void* pix, int src_f32, int C, int H, int W, int p, bf16_t* out, int Kpad, hipStream_t stream);
 int td_cast_pad_rows_launch(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad, hipStream_t stream);
+
+// temperature / top-p sampling over bf16 logits rows (sampler.hip): one workgroup per row, token ids to out_ids[rows]
+int td_sample_top_p_launch(const bf16_t* logits, long long ld, int rows, int vocab, float temperature, float top_p,
+                           unsigned long long seed, unsigned long long offset, int* out_ids, hipStream_t stream);

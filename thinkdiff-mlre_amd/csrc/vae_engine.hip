@@ -278,7 +278,7 @@ int td_vae_decode(td_vae* f, const void* packed_latents, int h, int w, float sca
   int H = h, W = w;
   const int P0 = H * W;
 
-  TDV_TRY(td_latents_to_nhwc_launch((const bf16_t*)packed_latents, f->T1, f->cfg.latent_channels, h, w, f->lat_pad, 1.0f / scaling_factor, shift_factor, s));
+  TDV_TRY(td_latents_to_nhwc_launch((const bf16_t*)packed_latents, f->T1, f->cfg.latent_channels, h, w, f->lat_pad, scaling_factor, shift_factor, s));
   TDV_TRY(conv3(s, f->T1, f->cin_w, f->cin_b, nullptr, f->X, H, W, f->lat_pad, cmid, 0));
 
   // ---- mid block ------------------------------------------------------------------------------------------

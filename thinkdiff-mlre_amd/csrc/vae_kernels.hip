@@ -190,7 +190,7 @@ int td_conv_pack_launch(const bf16_t* w, bf16_t* out, int Cout, int Cin, int Cou
 }
 
 // ---- FLUX packed latents [ (h/2)(w/2), 4C ] -> NHWC [h*w, Cpad] with z*mul + add (channels >= C zero) ---------
-__global__ void td_latents_to_nhwc_kernel(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float mul, float add) {
+__global__ void td_latents_to_nhwc_kernel(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float div, float add) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= h * w * Cpad) return;
   const int c = idx % Cpad, pix = idx / Cpad;
@@ -198,13 +198,14 @@ __global__ void td_latents_to_nhwc_kernel(const bf16_t* packed, bf16_t* out, int
   const int y = pix / w, x = pix % w;
   const int tok = (y >> 1) * (w >> 1) + (x >> 1);
   const int col = c * 4 + (y & 1) * 2 + (x & 1);
-  out[idx] = f2bf(bf2f(packed[(size_t)tok * (4 * C) + col]) * mul + add);
+  // latents / scaling_factor + shift_factor on bf16 tensors ([ext] pipeline_flux.py): the quotient rounds to bf16, then the sum
+  out[idx] = f2bf(__fadd_rn(rbf(__fdiv_rn(bf2f(packed[(size_t)tok * (4 * C) + col]), div)), add));
 }
 
-int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float mul, float add, hipStream_t stream) {
+int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float div, float add, hipStream_t stream) {
   TD_CHECK_ARG(C > 0 && h % 2 == 0 && w % 2 == 0 && Cpad >= C, "td_latents_to_nhwc: bad shape");
   const int n = h * w * Cpad;
-  hipLaunchKernelGGL(td_latents_to_nhwc_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, packed, out, C, h, w, Cpad, mul, add);
+  hipLaunchKernelGGL(td_latents_to_nhwc_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, packed, out, C, h, w, Cpad, div, add);
   TD_CHECK_LAUNCH();
   return 0;
 }

@@ -108,6 +108,7 @@ def _declare(L):
         "td_silu_mul_bf16": [vp, vp, i32, i32, vp],
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
+        "td_sample_top_p_bf16": [vp, i64, i32, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -239,10 +240,10 @@ def flux_pack_latents(lat):
     return out
 
 
-def flux_unpack_latents(x, C, H, W, mul=1.0, add=0.0):
-    """[(H/2)(W/2), 4C] bf16 -> [C,H,W] * mul + add"""
+def flux_unpack_latents(x, C, H, W, div=1.0, add=0.0):
+    """[(H/2)(W/2), 4C] bf16 -> bf16(bf16([C,H,W] / div) + add)"""
     out = torch.empty(C, H, W, dtype=torch.bfloat16, device=x.device)
-    check(lib().td_flux_pack_latents(ptr(x.contiguous()), ptr(out), C, H, W, 1, float(mul), float(add), stream_ptr()))
+    check(lib().td_flux_pack_latents(ptr(x.contiguous()), ptr(out), C, H, W, 1, float(div), float(add), stream_ptr()))
     return out
 
 
@@ -418,3 +419,14 @@ def norm_rows_quant_fp8(x, rms=False, eps=1e-6, w=None, split=0, shiftA=None, sc
     check(lib().td_norm_rows_quant_fp8(ptr(x), _rows(x), ptr(q), D, ptr(s), R, D, int(rms), float(eps), ptr(w), split,
                                        ptr(shiftA), ptr(scaleA), ptr(shiftB), ptr(scaleB), stream_ptr()))
     return q, s
+
+
+def sample_top_p(logits, temperature, top_p, seed, offset, out=None):
+    """logits bf16 [rows, vocab] (or [vocab]) -> int32 [rows] token ids on the device; no host synchronisation."""
+    x = logits if logits.dim() == 2 else logits[None]
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    check(lib().td_sample_top_p_bf16(ptr(x), x.stride(0), x.shape[0], x.shape[1], float(temperature), float(top_p),
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFFFFFFFFFF, ptr(out), stream_ptr()))
+    return out

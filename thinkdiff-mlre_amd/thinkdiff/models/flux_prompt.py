@@ -161,7 +161,8 @@ class FluxPipelineRewritePrompt:
         w = 2 * (int(width) // self.vae_scale_factor)
         dev = self._execution_device
         if latents is not None:
-            return latents.to(dev, torch.bfloat16).contiguous(), h, w
+            # the engine updates latents in place; diffusers never mutates the caller's tensor, so work on a copy
+            return latents.to(dev, torch.bfloat16).contiguous().clone(), h, w
         raw = torch.randn((batch, c, h, w), generator=generator, device=dev, dtype=torch.bfloat16)
         packed = torch.stack([_hip.flux_pack_latents(raw[b]) for b in range(batch)])
         return packed, h, w
@@ -223,7 +224,7 @@ class FluxPipelineRewritePrompt:
                 outs.append(x)
             elif output_type == "vae_input":  # _unpack_latents + (z / scaling_factor + shift_factor), no decode
                 outs.append(_hip.flux_unpack_latents(x, tr.config.in_channels // 4, h, w,
-                                                     1.0 / self.vae_scaling_factor, self.vae_shift_factor))
+                                                     self.vae_scaling_factor, self.vae_shift_factor))
             elif self.vae is None:
                 raise _hip.ThinkDiffHipError("no VAE loaded: call with output_type='latent' (packed latents) or "
                                              "'vae_input' (unpacked, scaled decoder input)")

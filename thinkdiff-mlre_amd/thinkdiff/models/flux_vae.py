@@ -75,9 +75,17 @@ class AutoencoderKLDecoder:
             raw = json.load(fh)
         fields = {f.name for f in dataclasses.fields(AutoencoderKLConfig)}
         m = cls(AutoencoderKLConfig(**{k: v for k, v in raw.items() if k in fields}), **kw)
+        seen = set()
         for fn in sorted(glob.glob(os.path.join(root, "*.safetensors"))):
             with safe_open(fn, framework="pt") as fh:
-                m.load_state_dict({k: fh.get_tensor(k) for k in fh.keys()}, strict=False)
+                part = {k: fh.get_tensor(k) for k in fh.keys()}
+            m.load_state_dict(part, strict=False)
+            seen.update(part)
+        # every decoder tensor must have arrived: an older VAE export (attention weights named query/key/value/proj_attn)
+        # would otherwise leave parts of the weight arena uninitialised and decode garbage without an error
+        missing = [k for k in m.param_table() if k not in seen]
+        if missing:
+            raise KeyError(f"VAE checkpoint at {root} lacks {len(missing)} decoder tensors, e.g. {missing[:3]}")
         return m
 
     def init_random(self, seed: int = 0, std: float = 0.02):

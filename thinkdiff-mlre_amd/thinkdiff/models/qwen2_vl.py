@@ -222,25 +222,39 @@ class Qwen2VLTextEngine:
         next_pos = int(pos.max()) + 1      # M-RoPE: generation continues one past the largest prompt position
         tok = torch.tensor(list(prompt_token_ids), dtype=torch.int32)
         prompt_hidden, logits = self.forward(pos, tok if inputs_embeds is None else None, inputs_embeds, 0, True, True)
-        out_ids, out_hidden = [], []
+        out_tok, out_hidden = [], []
         stops = set(sampling.stop_token_ids or [])
+        can_stop = forced_output_ids is None and (bool(stops) or ((not sampling.ignore_eos) and eos_token_id is not None))
+        key = None if forced_output_ids is not None else self._draw_sampler_key(generator)
+        if forced_output_ids is not None:
+            forced_dev = torch.tensor(list(forced_output_ids), dtype=torch.int32).to(self.device)
         for step in range(sampling.max_tokens):
             if forced_output_ids is not None:
                 if step >= len(forced_output_ids):
                     break
-                nxt = int(forced_output_ids[step])
+                nxt = forced_dev[step:step + 1]
             else:
-                nxt = self._sample(logits, sampling, generator)
-            out_ids.append(nxt)
+                nxt = _hip.sample_top_p(logits, sampling.temperature, sampling.top_p, key, step)     # device int32 [1], no host round trip
+            out_tok.append(nxt)
             # one token against the cache: the decode step (fused rope + cache write, decode attention, gated-MLP weight stream)
-            h1, lg = self.decode_batch([nxt], [[next_pos + step]] * 3, [n_p + step])
+            h1, lg = self.decode_batch(nxt, [[next_pos + step]] * 3, [n_p + step])
             logits = lg[0]
             out_hidden.append(h1)
-            done_eos = (not sampling.ignore_eos) and eos_token_id is not None and nxt == eos_token_id
-            if forced_output_ids is None and step + 1 >= sampling.min_tokens and (done_eos or nxt in stops):
-                break
+            if can_stop and step + 1 >= sampling.min_tokens:      # only now does the host need to see the token
+                t = int(nxt)
+                if ((not sampling.ignore_eos) and eos_token_id is not None and t == eos_token_id) or t in stops:
+                    break
         hs = torch.cat(out_hidden) if out_hidden else torch.empty(0, self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
+        out_ids = torch.cat(out_tok).tolist() if out_tok else []
         return {"prompt_hidden_states": prompt_hidden, "hidden_states": hs, "token_ids": out_ids}
+
+    @staticmethod
+    def _draw_sampler_key(generator: Optional[torch.Generator] = None) -> int:
+        """64-bit key of one generate() call's sampling stream, drawn from `generator` (default: torch's global CPU generator),
+        so `torch.manual_seed` / a seeded generator reproduce the sampled tokens and successive calls differ.  The HIP sampler
+        derives row r's draw for generated token t from (key, t, r) (td_sample_top_p_bf16)."""
+        dev = generator.device if generator is not None else "cpu"
+        return int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=dev))
 
     MAX_BATCH = 16
 
@@ -286,6 +300,7 @@ class Qwen2VLTextEngine:
                 rows.append(lg)
             logits = torch.stack(rows)              # [B, vocab], row i belongs to the sequence in slot i
         owner = list(range(B))                      # slot -> request index
+        key = None if forced_output_ids is not None else self._draw_sampler_key(generator)
         stops = set(sampling.stop_token_ids or [])
         step = 0
         while owner and step < sampling.max_tokens:
@@ -300,7 +315,8 @@ class Qwen2VLTextEngine:
                     n = len(owner)
                 toks = [int(forced_output_ids[owner[i]][step]) for i in range(n)]
             else:
-                toks = self._sample_batch(logits[:n], sampling, generator)
+                # one launch for all live rows (td_sample_top_p_bf16); the ids come to the host once per step for the bookkeeping below
+                toks = _hip.sample_top_p(logits[:n], sampling.temperature, sampling.top_p, key, step).tolist()
             pos = torch.tensor([[next_pos[i] for i in range(n)]] * 3, dtype=torch.int32)
             hid, logits = self.decode_batch(toks, pos, cache_len[:n])
             keep = []
@@ -331,34 +347,6 @@ class Qwen2VLTextEngine:
         owner[:] = [owner[i] for i in keep]
         cache_len[:] = [cache_len[i] for i in keep]
         next_pos[:] = [next_pos[i] for i in keep]
-
-    @staticmethod
-    def _sample_batch(logits: torch.Tensor, sp: SamplingParams, generator=None) -> List[int]:
-        """Row-wise temperature / top-p sampling on the device, one host round trip for the whole batch."""
-        x = logits.float()
-        if sp.temperature <= 0:
-            return x.argmax(dim=-1).tolist()
-        probs = torch.softmax(x / sp.temperature, dim=-1)
-        if sp.top_p < 1.0:
-            sp_, idx = torch.sort(probs, dim=-1, descending=True)
-            keep = (torch.cumsum(sp_, -1) - sp_) < sp.top_p
-            sp_ = torch.where(keep, sp_, torch.zeros_like(sp_))
-            pick = torch.multinomial(sp_ / sp_.sum(-1, keepdim=True), 1, generator=generator)
-            return idx.gather(1, pick)[:, 0].tolist()
-        return torch.multinomial(probs, 1, generator=generator)[:, 0].tolist()
-
-    @staticmethod
-    def _sample(logits: torch.Tensor, sp: SamplingParams, generator=None) -> int:
-        x = logits.float()
-        if sp.temperature <= 0:
-            return int(x.argmax())
-        probs = torch.softmax(x / sp.temperature, dim=-1)
-        if sp.top_p < 1.0:
-            sp_, idx = torch.sort(probs, descending=True)
-            keep = (torch.cumsum(sp_, 0) - sp_) < sp.top_p
-            sp_ = torch.where(keep, sp_, torch.zeros_like(sp_))
-            return int(idx[torch.multinomial(sp_ / sp_.sum(), 1, generator=generator)])
-        return int(torch.multinomial(probs, 1, generator=generator))
 
 
 def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 4 * 28 * 28, max_pixels: int = 16384 * 28 * 28):
