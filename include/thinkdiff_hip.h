@@ -111,7 +111,8 @@ int td_timestep_sincos(const float* t, int n, void* out, void* stream);
 int td_euler_step_bf16(void* x, const void* v, float dt, int64_t n, void* stream);
 /* FluxPipeline._pack_latents (unpack=0: [C,H,W] -> [(H/2)(W/2),4C]) / _unpack_latents (unpack=1, with
  * out = bf16(bf16(in / div) + add), i.e. the `latents / scaling_factor + shift_factor` on bf16 tensors that precedes
- * vae.decode in [ext] pipeline_flux.py: quotient and sum each round to bf16; div = 1, add = 0 is a pure unpack). */
+ * vae.decode in [ext] pipeline_flux.py, with torch's CPU scalar rules: fp32 divisor, addend cast to bf16, quotient and sum
+ * each round to bf16; div = 1, add = 0 is a pure unpack). */
 int td_flux_pack_latents(const void* src, void* dst, int C, int H, int W, int unpack, float div, float add, void* stream);
 /* ThinkDiff-CLIP token pooling (blip_vision_t5_decoder.py:620-637): [1+G*G,C] -> [1+(G/2)^2,C]. */
 int td_cls_avgpool2_bf16(const void* x, void* y, int G, int C, void* stream);

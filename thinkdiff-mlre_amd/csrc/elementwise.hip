@@ -292,7 +292,7 @@ __global__ void td_euler_step_kernel(bf16_t* x, const bf16_t* v, float dt, int n
   unpack8(((const u32x4_t*)x)[idx], a);
   unpack8(((const u32x4_t*)v)[idx], b);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = __fadd_rn(a[i], __fmul_rn(dt, b[i]));   // torch: sample + dt * model_output, two fp32 roundings (no fma)
+  for (int i = 0; i < 8; ++i) a[i] = mul_then_add(a[i], dt, b[i]);   // torch: sample + dt * model_output, two fp32 roundings (no fma)
   ((u32x4_t*)x)[idx] = pack8(a);
 }
 
@@ -318,7 +318,9 @@ __global__ void td_flux_pack_kernel(const bf16_t* src, bf16_t* dst, int C, int H
   const int wj = W / 2;
   const int i = tok / wj, j = tok % wj;
   const size_t sp = ((size_t)c * H + (2 * i + di)) * W + (2 * j + dj);
-  if (unpack) dst[sp] = f2bf(__fadd_rn(rbf(__fdiv_rn(bf2f(src[idx]), div)), add));   // (z / scaling) + shift: two bf16 torch ops, each rounds
+  // (z / scaling) + shift as two bf16 torch (CPU) ops: the quotient rounds to bf16 (fp32 scalar divisor), the python-scalar
+  // addend is cast to the tensor dtype first, the sum rounds to bf16
+  if (unpack) dst[sp] = f2bf(__fadd_rn(rbf(__fdiv_rn(bf2f(src[idx]), div)), rbf(add)));
   else dst[idx] = src[sp];
 }
 

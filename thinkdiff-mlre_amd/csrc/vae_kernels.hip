@@ -199,7 +199,8 @@ __global__ void td_latents_to_nhwc_kernel(const bf16_t* packed, bf16_t* out, int
   const int tok = (y >> 1) * (w >> 1) + (x >> 1);
   const int col = c * 4 + (y & 1) * 2 + (x & 1);
   // latents / scaling_factor + shift_factor on bf16 tensors ([ext] pipeline_flux.py): the quotient rounds to bf16, then the sum
-  out[idx] = f2bf(__fadd_rn(rbf(__fdiv_rn(bf2f(packed[(size_t)tok * (4 * C) + col]), div)), add));
+  // (torch CPU semantics: fp32 scalar divisor, python-scalar addend cast to bf16 first)
+  out[idx] = f2bf(__fadd_rn(rbf(__fdiv_rn(bf2f(packed[(size_t)tok * (4 * C) + col]), div)), rbf(add)));
 }
 
 int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float div, float add, hipStream_t stream) {
