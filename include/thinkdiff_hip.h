@@ -81,8 +81,10 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
                       int64_t ldkv, int64_t kv_bstride, void* o, int64_t ldo, int64_t o_bstride,
                       int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,
                       int causal, void* stream);
-/* Selects the kernel structure td_attention_bf16 launches: 0 = shipped, 1 = the earlier lockstep kernel
- * kept for in-process A/B measurements.  Returns the previous value. */
+/* Selects the kernel structure td_attention_bf16 launches: 0 = shipped (joint attention with more (query tile, head) items
+ * than CUs runs as one round of persistent workgroups over equal KV-tile ranges; the first such call on a device allocates a
+ * 35 MB hand-off workspace, so make it before capturing into a hipGraph), 1 = one workgroup per item for every shape, 2 = the
+ * persistent form without the XCD-aware range order.  1 and 2 exist for in-process A/B measurements.  Returns the previous value. */
 int td_attention_set_variant(int variant);
 
 /* ---- row kernels (each is also used inside the FLUX engine) -------------------------------------- */

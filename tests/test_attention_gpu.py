@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1], ids=["lean", "lockstep"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "one_wg_per_item", "streamk_no_remap"], autouse=True)
 def all_variants(request, hip):
     """Every kernel structure behind td_attention_bf16 must pass every case."""
     prev = hip.lib().td_attention_set_variant(request.param)
@@ -53,6 +53,27 @@ def test_joint_attention_inplace_qkv(hip, S, H):
     torch.cuda.synchronize()
     c = qkv
     _check(out, _ref(c[:, :, :H * 128], c[:, :, H * 128:2 * H * 128], c[:, :, 2 * H * 128:], H, H, False))
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 4289, 24), (1, 1000, 80), (2, 520, 50), (1, 4354, 24)])
+def test_joint_attention_more_items_than_cus(hip, B, S, H):
+    """More (query tile, head) items than CUs: the stream-K form (equal ranges of KV-tile iterations per persistent workgroup,
+    items split across two workgroups merged through the hand-off workspace).  FLUX config 2 (S = 4289) and config 5 (S = 4354)
+    shapes, a ragged 4-tile case and a batched one.  Run twice: the second launch finds the flags cleared by the first."""
+    g = torch.Generator().manual_seed(S + H)
+    qkv = torch.randn(B, S, 3 * H * 128, generator=g).bfloat16()
+    d = qkv.cuda()
+    q, k, v = d[:, :, :H * 128], d[:, :, H * 128:2 * H * 128], d[:, :, 2 * H * 128:]
+    outs = []
+    for _ in range(2):
+        out = torch.zeros(B, S, H * 128, dtype=torch.bfloat16, device="cuda")
+        hip.attention(q, k, v, out, H, H)
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.cat([_ref(qkv[:, :, h * 128:(h + 1) * 128], qkv[:, :, (H + h) * 128:(H + h + 1) * 128], qkv[:, :, (2 * H + h) * 128:(2 * H + h + 1) * 128], 1, 1, False)
+                     for h in range(H)], dim=2)
+    _check(outs[0], ref)
 
 
 def test_attention_peaked_rows(hip):

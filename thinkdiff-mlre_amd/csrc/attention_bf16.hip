@@ -18,6 +18,8 @@
 //    (off(row,ch) = 256 row + 16 (ch ^ ((row&3)<<2 | (row>>2)&3))), applied on the DMA source side.
 //  * q/k/v are read in place from the projection output ([S, ld] rows, head h at column h*128):
 //    no head-major re-layout pass exists anywhere on the path.
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "td_common.h"
@@ -57,239 +59,12 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 }  // namespace
 
-template <bool CAUSAL, int NWAVES, bool STAGGER>
-__global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_kernel(const TdAttnParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int VBUFS = STAGGER ? 3 : 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K tile x 2 | V tile x VBUFS]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h5 = lane >> 5;       // lane half
-  const int l31 = lane & 31;
-
-  const int qblk = blockIdx.x;
-  const int head = blockIdx.y;
-  const int batch = blockIdx.z;
-  const int kvhead = head / p.q_per_kv;
-  const int q0 = qblk * (NWAVES * Q_WAVE) + wid * Q_WAVE;  // first query row of this wave
-
-  const bf16_t* Qb = p.Q + (size_t)batch * p.q_bstride;
-  const bf16_t* Kb = p.K + (size_t)batch * p.kv_bstride;
-  const bf16_t* Vb = p.V + (size_t)batch * p.kv_bstride;
-  bf16_t* Ob = p.O + (size_t)batch * p.o_bstride;
-
-  const unsigned q_bytes = (unsigned)(((long long)(p.Sq - 1) * p.ldq + p.Hq * D) * 2);
-  const unsigned kv_bytes = (unsigned)(((long long)(p.Skv - 1) * p.ldkv + p.Hkv * D) * 2);
-  __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, q_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, kv_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, kv_bytes, 0x00020000);
-
-  // ---- number of KV tiles this workgroup visits ----------------------------------------------
-  int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
-  if (CAUSAL) {
-    const int last_q = min(p.Sq, (qblk + 1) * NWAVES * Q_WAVE) - 1 + p.causal_offset;
-    nt = min(nt, last_q / KV_TILE + 1);
-  }
-
-  // ---- staging (LDS-DMA): 16 groups of 4 rows per tile, NWAVES waves share them ---------------
-  constexpr int GROUPS = KV_TILE / 4;
-  constexpr int SG = (GROUPS + NWAVES - 1) / NWAVES;
-  const int srow = lane >> 4;  // row inside the 4-row group
-  unsigned voffK[SG];
-#pragma unroll
-  for (int s = 0; s < SG; ++s) {
-    const int g = wid + NWAVES * s;
-    const int swz = (srow << 2) | (g & 3);
-    const int chunk = (lane & 15) ^ swz;
-    voffK[s] = (unsigned)(g * 4 + srow) * (unsigned)p.ldkv * 2u + (unsigned)(kvhead * D + chunk * 8) * 2u;
-  }
-  auto stage = [&](int kslot, int vslot_, int t) {
-    char* kdst = smem + kslot * TILE_BYTES;
-    char* vdst = smem + 2 * TILE_BYTES + vslot_ * TILE_BYTES;
-    const unsigned tile_off = (unsigned)t * KV_TILE * (unsigned)p.ldkv * 2u;
-#pragma unroll
-    for (int s = 0; s < SG; ++s) {
-      const int g = wid + NWAVES * s;
-      if (GROUPS % NWAVES == 0 || g < GROUPS) {
-        // row part stays in voffset so the descriptor range check sees it: keys >= Skv read as 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(kdst + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(vdst + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
-      }
-    }
-  };
-
-  stage(0, 0, 0);
-
-  // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + l31][16 ks + 8 h5 .. +8] -----
-  bf16x8_t qf[8];
-  {
-    const unsigned qoff = (unsigned)(q0 + l31) * (unsigned)p.ldq * 2u + (unsigned)(head * D + 8 * h5) * 2u;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + ks * 32, 0, 0);
-      qf[ks] = __builtin_bit_cast(bf16x8_t, v);
-    }
-  }
-
-  // ---- per-lane LDS read offsets ----------------------------------------------------------------
-  // K row read: row = kb*32 + l31, chunk = 2 ks + h5
-  const int ksw = ((lane & 3) << 2) | ((lane >> 2) & 3);
-  const int krow_off = l31 * 256;
-  // V transposed read: lane i=lane&15 of its 16-lane group addresses row q=i>>2, cols 4p..4p+3 (p=i&3)
-  const int vq = (lane & 15) >> 2, vp = lane & 3;
-  const int vrow_base = 4 * h5 + vq;                 // + kb*32 + 16 s + 8 jj
-  const int vchunk_base = 2 * ((lane >> 4) & 1) + (vp >> 1);  // + 4 db
-
-  f32x16_t o[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -1e30f;   // row max the exponentials are taken against (raw score units)
-  float l_run = 0.f;      // this lane-half's partial row sum
-  const float c = p.scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c)
-  const int q_pos = q0 + l31 + p.causal_offset;   // causal: keys <= q_pos visible
-  bf16x8_t pf[2][2];      // [kb][s] B-operand fragments of P^T (live across the barrier for the deferred half)
-
-  // O^T += V^T . P^T for one KV tile
-  auto pv = [&](const char* vbuf) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          bf16x4_t v01[2];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int row = kb * 32 + 16 * s + 8 * jj + vrow_base;
-            const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-            const int off = row * 256 + (((4 * db + vchunk_base) ^ swz) << 4) + 8 * (vp & 1);
-            v01[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(vbuf + off));
-          }
-          bf16x8_t vf;
-          vf[0] = v01[0][0]; vf[1] = v01[0][1]; vf[2] = v01[0][2]; vf[3] = v01[0][3];
-          vf[4] = v01[1][0]; vf[5] = v01[1][1]; vf[6] = v01[1][2]; vf[7] = v01[1][3];
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], o[db], 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  // Ping-pong: the two waves that share a SIMD (w and w + NWAVES/2) run half a tile apart.  The second
-  // half of the workgroup defers each tile's P.V product until after the next barrier, so its matrix work
-  // overlaps the first half's softmax (VALU) and vice versa; in lockstep both waves would sit in their
-  // softmax at the same time with the matrix pipe idle.  The deferred product still reads V(t-1) while
-  // tile t+1 is being staged, hence the 3-deep V ring (K stays 2-deep).
-  const bool deferred = STAGGER && wid >= NWAVES / 2;
-  int vslot = 0;  // t % VBUFS
-
-  for (int t = 0; t < nt; ++t) {
-    __syncthreads();  // vmcnt(0) + barrier: tile t landed; K buffer (t+1)&1 and V slot (t+1)%VBUFS are free
-    const int vnext = vslot + 1 == VBUFS ? 0 : vslot + 1;
-    if (t + 1 < nt) stage((t + 1) & 1, vnext, t + 1);
-    const char* kbuf = smem + (t & 1) * TILE_BYTES;
-    const char* vbuf = smem + 2 * TILE_BYTES + vslot * TILE_BYTES;
-    if (deferred && t > 0) pv(smem + 2 * TILE_BYTES + (vslot == 0 ? VBUFS - 1 : vslot - 1) * TILE_BYTES);
-    vslot = vnext;
-
-    // ---- S^T = K . Q^T ------------------------------------------------------------------------
-    f32x16_t st[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(kbuf + kb * 32 * 256 + krow_off + (((2 * ks + h5) ^ ksw) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-      }
-    }
-
-    // ---- masking: tail keys (>= Skv) and causal --------------------------------------------------
-    const int key0 = t * KV_TILE;
-    const bool need_mask = (key0 + KV_TILE > p.Skv) || (CAUSAL && key0 + KV_TILE - 1 > q0 + p.causal_offset);
-    if (need_mask) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-          const bool dead = (key >= p.Skv) || (CAUSAL && key > q_pos);
-          if (dead) st[kb][r] = -INFINITY;
-        }
-    }
-
-    // ---- online softmax (row = query = lane & 31, split over the two lane halves) -------------
-    float mx = st[0][0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = max3(mx, st[0][r], st[1][r]);
-    mx = half_swap_max(mx);
-    // Deferred rescale: O and l are rescaled only when some row's max grew by more than 2^RESCALE_LOG2
-    // (P <= 2^8 then, harmless in the fp32 accumulators and in bf16 P); rows are otherwise exponentiated
-    // against their stale max.  Every row is finite after tile 0: m_run starts at -1e30 so tile 0 rescales.
-    constexpr float RESCALE_LOG2 = 8.0f;
-    if (__any((mx - m_run) * c > RESCALE_LOG2)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    const float mc = m_run * c;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        u32x4_t pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s + 2 * j] * c - mc);
-          const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s + 2 * j + 1] * c - mc);
-          psum += p0 + p1;
-          pk[j] = pack_bf2(p0, p1);
-        }
-        pf[kb][s] = __builtin_bit_cast(bf16x8_t, pk);
-      }
-    }
-    l_run += psum;
-
-    if (!deferred) pv(vbuf);
-  }
-  if (deferred) pv(smem + 2 * TILE_BYTES + (vslot == 0 ? VBUFS - 1 : vslot - 1) * TILE_BYTES);
-
-  // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] --------------------
-  const float l_tot = half_swap_sum(l_run);
-  const float inv = 1.0f / l_tot;
-  const int q = q0 + l31;
-  if (q < p.Sq) {
-    bf16_t* op = Ob + (size_t)q * p.ldo + head * D + 4 * h5;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2_t w;
-        w[0] = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-        w[1] = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-        *(u32x2_t*)(op + db * 32 + 8 * g) = w;
-      }
-  }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------
-// Lockstep structure with a lean instruction stream.  rocprofv3 PMC on the kernel above (S=4289, 24 heads):
-// 7.2 VALU instructions per MFMA and the SIMD's issue slots, not the matrix pipe (50 % busy), set the pace --
-// two thirds of that VALU work was LDS address arithmetic (XOR-swizzled addresses recomputed per read) and
-// accumulator zeroing.  Here every per-lane LDS address lives in a register for the whole kernel (8 for the
-// K row reads, 8 for the V transposed reads; k-block / k-step / tile-slot parts are instruction immediates
-// and one XOR per register per tile flips the double-buffer slot).
+// One workgroup per (256-row query tile, head, batch).  Lean instruction stream: rocprofv3 PMC on the first form of this
+// kernel (S=4289, 24 heads) showed 7.2 VALU instructions per MFMA and the SIMD's issue slots, not the matrix pipe (50 % busy),
+// setting the pace -- two thirds of that VALU work was LDS address arithmetic (XOR-swizzled addresses recomputed per read) and
+// accumulator zeroing.  Here every per-lane LDS address lives in a register for the whole kernel (8 for the K row reads,
+// 8 for the V transposed reads; k-block / k-step / tile-slot parts are instruction immediates).
 // ---------------------------------------------------------------------------------------------
 template <bool CAUSAL, int NWAVES, bool BIAS = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(const TdAttnParams p) {
@@ -540,6 +315,358 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stream-K form of the kernel above for joint (non-causal) attention: the launch is ONE round of persistent workgroups.
+//
+// FLUX at 1024^2: 17 query tiles x 24 heads = 408 workgroups of 67 KV tiles each on 256 CUs -- two rounds, the second 59 %
+// empty (20 % of the kernel's time).  Here the 408 x 67 (item, KV tile) iterations are cut into G equal contiguous ranges,
+// one per workgroup, G = number of CUs.  A range starts inside an item and ends inside another, so a workgroup runs
+//   [tail part of item a : KV tiles kb..nt) ] [whole items ...] [head part of item z : KV tiles 0..ke) ]
+// and every item is split over at most two workgroups (a range is longer than an item).  The workgroup that owns an
+// item's TAIL part meets it first thing in its life and hands its un-normalised state (O accumulators, row max, row sum:
+// 68 floats per lane) to the owner of the HEAD part through a workspace slot; that owner reaches the item last, merges the
+// two online-softmax states exactly as two KV tiles are merged inside the loop, normalises and stores.  The hand-off is the
+// placement-independent recipe (guide 6, Guideline 16 R1): write-through (sc1) 16-byte stores, every storing wave drains
+// (s_waitcnt vmcnt(0)), workgroup barrier, one lane stores the flag (agent scope); the consumer polls that one word relaxed,
+// then ONE agent-scope acquire, s_waitcnt, barrier, plain loads.  The consumer clears the flag; the launcher zeroes the flag
+// block when the workspace is created.  Producer work is the FIRST thing a workgroup does and the wait the LAST, so with every
+// workgroup resident (G <= CUs) the wait is normally already satisfied; the spin is bounded all the same and a time-out is
+// recorded in the workspace header for the host (td_attn_launch refuses further launches once it is set).
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int SK_SLOT_FLOATS = 8 * 64 * 68;          // per workgroup: 8 waves x 64 lanes x (64 O + m + l + 2 pad) floats
+constexpr int SK_HEADER_WORDS = 1024;                 // [0]: time-out word, [16 + r]: flag of logical range r
+struct SkWorkspace { float* slots; unsigned* header; int ranges; };
+}  // namespace
+
+template <int NWAVES, bool XCD_REMAP>
+__global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kernel(const TdAttnParams p, float* __restrict__ ws_slots,
+                                                                                  unsigned* __restrict__ ws_header, const int n_qblk, const int nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5;
+  const int l31 = lane & 31;
+
+  // logical range of this workgroup: with XCD_REMAP, workgroups that share an XCD (equal blockIdx % 8 under round-robin
+  // placement; speed only) take neighbouring ranges = neighbouring query tiles of the same heads = the same K/V in that L2
+  const int G = gridDim.x;
+  int r = blockIdx.x;
+  if constexpr (XCD_REMAP) {
+    const int q8 = G >> 3, r8 = G & 7, xcd = r & 7;
+    r = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (r >> 3);
+  }
+  const long long total = (long long)n_qblk * p.Hq * p.batch * nt;
+  long long it = total * r / G;
+  const long long it_end = total * (r + 1) / G;
+
+  const int Skv = p.Skv;
+  constexpr int GROUPS = KV_TILE / 4;
+  constexpr int SG = (GROUPS + NWAVES - 1) / NWAVES;
+  const int srow = lane >> 4;
+  const float c = p.scale * 1.4426950408889634f;
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // ---- resident per-lane LDS byte addresses of slot 0 (the other slot is an immediate offset in the tile body) ----
+  const unsigned lds0 = (unsigned)(uintptr_t)(TD_LDS char*)smem;
+  unsigned ka[8];
+  {
+    const unsigned ksw = ((lane & 3) << 2) | ((lane >> 2) & 3);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) ka[ks] = lds0 + l31 * 256 + (((2 * ks + h5) ^ ksw) << 4);
+  }
+  unsigned va[2][4];
+  {
+    const unsigned vq = (lane & 15) >> 2, vp = lane & 3;
+    const unsigned vchunk = 2 * ((lane >> 4) & 1) + (vp >> 1);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const unsigned swz = (vq << 2) | ((2 * jj + h5) & 3);
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+        va[jj][db] = lds0 + 2 * TILE_BYTES + (4 * h5 + vq + 8 * jj) * 256 + (((4 * db + vchunk) ^ swz) << 4) + 8 * (vp & 1);
+    }
+  }
+
+  while (it < it_end) {
+    // ---- the part of an item this workgroup runs now: KV tiles [kb, ke) of item `item` -------------------------------
+    const int item = (int)(it / nt);
+    const int kb = (int)(it - (long long)item * nt);
+    const int ke = (int)min((long long)nt, kb + (it_end - it));
+    __builtin_assume(ke > kb);       // a part is never empty
+    it += ke - kb;
+    const int qblk = item % n_qblk;
+    const int hb = item / n_qblk;
+    const int head = hb % p.Hq, batch = hb / p.Hq;
+    const int kvhead = head / p.q_per_kv;
+    const int q0 = qblk * (NWAVES * Q_WAVE) + wid * Q_WAVE;
+
+    const bf16_t* Qb = p.Q + (size_t)batch * p.q_bstride;
+    const bf16_t* Kb = p.K + (size_t)batch * p.kv_bstride;
+    const bf16_t* Vb = p.V + (size_t)batch * p.kv_bstride;
+    const unsigned q_bytes = (unsigned)(((long long)(p.Sq - 1) * p.ldq + p.Hq * D) * 2);
+    const unsigned kv_bytes = (unsigned)(((long long)(Skv - 1) * p.ldkv + p.Hkv * D) * 2);
+    __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qb, 0, q_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, kv_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, kv_bytes, 0x00020000);
+
+    unsigned voffK[SG];
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
+      const int g = wid + NWAVES * s;
+      const int swz = (srow << 2) | (g & 3);
+      const int chunk = (lane & 15) ^ swz;
+      voffK[s] = (unsigned)(g * 4 + srow) * (unsigned)p.ldkv * 2u + (unsigned)(kvhead * D + chunk * 8) * 2u;
+    }
+    auto stage = [&](int slot, int t) {
+      const unsigned tile_off = (unsigned)t * KV_TILE * (unsigned)p.ldkv * 2u;
+#pragma unroll
+      for (int s = 0; s < SG; ++s) {
+        const int g = wid + NWAVES * s;
+        if (GROUPS % NWAVES == 0 || g < GROUPS) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(smem + slot * TILE_BYTES + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(smem + (2 + slot) * TILE_BYTES + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+        }
+      }
+    };
+    __syncthreads();          // the previous part's last tile is no longer read by any wave
+    stage(0, kb);
+
+    bf16x8_t qf[8];
+    {
+      const unsigned qoff = (unsigned)(q0 + l31) * (unsigned)p.ldq * 2u + (unsigned)(head * D + 8 * h5) * 2u;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + ks * 32, 0, 0);
+        qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    }
+
+    f32x16_t o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) o[db][rr] = 0.f;
+    float m_run = -1e30f;
+    float l_run = 0.f;
+
+    auto tile = [&](const int t, auto slot_tag) {
+      constexpr unsigned SLOT = decltype(slot_tag)::value;
+      constexpr unsigned PO = SLOT * TILE_BYTES;
+      __syncthreads();  // vmcnt(0) + barrier: tile t landed; the other slot is no longer read
+      if (t + 1 < ke) stage(SLOT ^ 1, t + 1);
+
+      f32x16_t st[2];
+      {
+        constexpr int KPF = 2;
+        auto kread = [&](int e) {   // e = kb * 8 + ks
+          return *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e & 7] + PO + (e >> 3) * 32 * 256);
+        };
+        bf16x8_t kf[16];
+#pragma unroll
+        for (int e = 0; e < KPF; ++e) kf[e] = kread(e);
+        __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
+          st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], (e & 7) == 0 ? zero16 : st[e >> 3], 0, 0, 0);
+          if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+
+      const int key0 = t * KV_TILE;
+      if (key0 + KV_TILE > Skv) {        // last tile: keys >= Skv are masked
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int key = key0 + kk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h5;
+            if (key >= Skv) st[kk][rr] = -INFINITY;
+          }
+      }
+
+      float mx = st[0][0];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) mx = max3(mx, st[0][rr], st[1][rr]);
+      mx = half_swap_max(mx);
+      constexpr float RESCALE_LOG2 = 8.0f;
+      if (__any((mx - m_run) * c > RESCALE_LOG2)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) o[db][rr] *= alpha;
+      }
+      const float mc = m_run * c;
+      float psum = 0.f;
+      bf16x8_t pf[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u32x4_t pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p0 = __builtin_amdgcn_exp2f(st[kk][8 * s2 + 2 * j] * c - mc);
+            const float p1 = __builtin_amdgcn_exp2f(st[kk][8 * s2 + 2 * j + 1] * c - mc);
+            psum += p0 + p1;
+            pk[j] = pack_bf2(p0, p1);
+          }
+          pf[kk][s2] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+      }
+      l_run += psum;
+
+      {
+        constexpr int VPF = 2;
+        auto vread = [&](int e, int jj) {   // e = (kb * 2 + s) * 4 + db
+          return __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(uintptr_t)(va[jj][e & 3] + PO + (e >> 2) * 16 * 256));
+        };
+        bf16x4_t v0[16], v1[16];
+#pragma unroll
+        for (int e = 0; e < VPF; ++e) { v0[e] = vread(e, 0); v1[e] = vread(e, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * VPF, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (e + VPF < 16) { v0[e + VPF] = vread(e + VPF, 0); v1[e + VPF] = vread(e + VPF, 1); }
+          bf16x8_t vf;
+          vf[0] = v0[e][0]; vf[1] = v0[e][1]; vf[2] = v0[e][2]; vf[3] = v0[e][3];
+          vf[4] = v1[e][0]; vf[5] = v1[e][1]; vf[6] = v1[e][2]; vf[7] = v1[e][3];
+          o[e & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[e >> 3][(e >> 2) & 1], o[e & 3], 0, 0, 0);
+          if (e + VPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+    };
+    {
+      int t = kb;
+      for (; t + 1 < ke; t += 2) {
+        tile(t, std::integral_constant<unsigned, 0>{});
+        tile(t + 1, std::integral_constant<unsigned, 1>{});
+      }
+      if (t < ke) tile(t, std::integral_constant<unsigned, 0>{});
+    }
+    // ---- what happens to the state: hand it over, merge a handed-over one, or just finish -------------------------------
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)ws_slots, 0, (unsigned)G * SK_SLOT_FLOATS * 4u, 0x00020000);
+    const unsigned lane_off = ((unsigned)wid * 17u * 64u + (unsigned)lane) * 16u;      // [wave][chunk 0..16][lane] x 16 bytes
+    if (kb > 0) {
+      // TAIL part (always runs to the item's end): publish into slot r.  Write-through stores, drained by every wave.
+      const unsigned base = (unsigned)r * (SK_SLOT_FLOATS * 4u) + lane_off;
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) {
+        const u32x4_t v = {as_u32(o[q4 >> 2][4 * (q4 & 3)]), as_u32(o[q4 >> 2][4 * (q4 & 3) + 1]),
+                           as_u32(o[q4 >> 2][4 * (q4 & 3) + 2]), as_u32(o[q4 >> 2][4 * (q4 & 3) + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsS, base + q4 * 1024u, 0, 16);       // aux 16 = sc1
+      }
+      const u32x4_t ml = {as_u32(m_run), as_u32(l_run), 0u, 0u};
+      __builtin_amdgcn_raw_buffer_store_b128(ml, rsS, base + 16 * 1024u, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(ws_header + 16 + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (ke < nt) {
+      // HEAD part: the rest of the item was run by the owner of logical range r + 1, as the first thing it did
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(ws_header + 16 + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 24)) {                      // seconds: the producer never ran; record it and stop waiting
+            __hip_atomic_store(ws_header, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned base = (unsigned)(r + 1) * (SK_SLOT_FLOATS * 4u) + lane_off;
+      const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(rsS, base + 16 * 1024u, 0, 0);
+      const float m2 = as_f32(ml[0]), l2 = as_f32(ml[1]);
+      const float mm = fmaxf(m_run, m2);
+      const float a1 = __builtin_amdgcn_exp2f((m_run - mm) * c), a2 = __builtin_amdgcn_exp2f((m2 - mm) * c);
+      l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsS, base + q4 * 1024u, 0, 0);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+          o[q4 >> 2][4 * (q4 & 3) + k4] = o[q4 >> 2][4 * (q4 & 3) + k4] * a1 + as_f32(v[k4]) * a2;
+      }
+      __syncthreads();          // every wave has its copy: the flag may be cleared for the next launch
+      if (tid == 0) __hip_atomic_store(ws_header + 16 + r + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] ------------------------------------------
+    const float l_tot = half_swap_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < p.Sq) {
+      bf16_t* op = p.O + (size_t)batch * p.o_bstride + (size_t)q * p.ldo + head * D + 4 * h5;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t w;
+          w[0] = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          w[1] = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *(u32x2_t*)(op + db * 32 + 8 * g) = w;
+        }
+    }
+  }
+#endif
+}
+
+namespace {
+
+// Per-device stream-K workspace (35 MB of slots + a 4 KB header), created on the first launch that needs it -- call
+// td_attention_bf16 once on a device before capturing it into a hipGraph.
+int sk_workspace(int dev, int ranges, hipStream_t stream, SkWorkspace* out) {
+  static std::mutex mu;
+  static SkWorkspace ws[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  SkWorkspace& w = ws[dev & 63];
+  if (!w.slots || w.ranges < ranges) {
+    if (w.slots) { TD_CHECK_HIP(hipFree(w.slots)); TD_CHECK_HIP(hipFree(w.header)); w = SkWorkspace{}; }
+    TD_CHECK_HIP(hipMalloc((void**)&w.slots, (size_t)ranges * SK_SLOT_FLOATS * sizeof(float)));
+    TD_CHECK_HIP(hipMalloc((void**)&w.header, SK_HEADER_WORDS * sizeof(unsigned)));
+    TD_CHECK_HIP(hipMemset(w.header, 0, SK_HEADER_WORDS * sizeof(unsigned)));
+    w.ranges = ranges;
+  }
+  *out = w;
+  return 0;
+}
+
+int device_cus(int dev) {
+  static std::atomic<int> cus[64] = {};
+  int n = cus[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n = prop.multiProcessorCount;
+    cus[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+template <typename K>
+int set_lds_attr_once(K kernel, int bytes, std::atomic<unsigned long long>& done, int dev) {
+  if (!((done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+  }
+  return 0;
+}
+
+}  // namespace
+
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.head_dim == D, "td_attention: head_dim=%d unsupported (only 128)", p.head_dim);
   TD_CHECK_ARG(p.Sq > 0 && p.Skv > 0 && p.Hq > 0 && p.Hkv > 0 && p.batch > 0, "td_attention: empty problem");
@@ -553,34 +680,53 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
     return td_attn_decode_launch(p, stream);
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
-  // variant 0 (shipped): lean instruction stream (resident LDS addresses, prefetched fragments);
-  // variant 1: the first lockstep kernel, kept for in-process A/B.  Structures that lost the A/B on MI355X
-  // and were removed: ping-pong wave halves with a 3-deep V ring (-9 %), 4-wave workgroups two per CU (-35 %),
-  // intra-wave QK^T(t+1) / softmax(t) software pipelining on the fat instruction stream (-6 %).
+  // Structures that lost the in-process A/B on MI355X and were removed: ping-pong wave halves with a 3-deep V ring (-9 %),
+  // 4-wave workgroups two per CU (-35 %), intra-wave QK^T(t+1) / softmax(t) software pipelining (-6 %), the first
+  // lockstep kernel with per-read address arithmetic (-15 %).
   constexpr int NW = 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<false, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_kernel<true, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<false, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_attn_fwd_d128_lean_kernel<true, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
-    attr_set = true;
-  }
+  constexpr int lds = 4 * TILE_BYTES;
+  int dev = 0;
+  TD_CHECK_HIP(hipGetDevice(&dev));
+  static std::atomic<unsigned long long> a0{0}, a1{0}, a2{0}, a3{0}, a4{0}, a5{0};
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
-  const int lds = 4 * TILE_BYTES;
   if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
   if (p.kv_lens) TD_CHECK_ARG(p.causal && !p.bias, "td_attention: per-sequence kv lengths exist for the causal kernel only");
-  if (p.variant == 1 && !p.bias && !p.kv_lens) {
-    if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_kernel<true, NW, false>), grid, dim3(NW * 64), lds, stream, q);
-    else hipLaunchKernelGGL((td_attn_fwd_d128_kernel<false, NW, false>), grid, dim3(NW * 64), lds, stream, q);
-  } else if (p.bias) {   // separate instantiation: the score-bias loads must not touch the hot no-bias instruction stream
-    if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW, true>), grid, dim3(NW * 64), lds, stream, q);
-    else hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
+
+  // joint attention with more workgroups than CUs: one round of persistent workgroups over equal (item, KV tile) ranges.
+  // variant 1 = the one-workgroup-per-item kernel for every shape (in-process A/B); variant 2 = stream-K without the XCD remap.
+  const int n_items = (int)(grid.x * grid.y * grid.z);
+  const int cus = device_cus(dev);
+  if (!p.causal && !p.bias && !p.kv_lens && p.variant != 1 && cus > 0 && n_items > cus && cus + 16 < SK_HEADER_WORDS) {
+    SkWorkspace ws;
+    const int rc = sk_workspace(dev, cus, stream, &ws);
+    if (rc) return rc;
+    const int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
+    if (p.variant == 2) {
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, false>, lds, a4, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, false>), dim3(cus), dim3(NW * 64), lds, stream, q, ws.slots, ws.header, (int)grid.x, nt);
+    } else {
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true>, lds, a5, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true>), dim3(cus), dim3(NW * 64), lds, stream, q, ws.slots, ws.header, (int)grid.x, nt);
+    }
+    TD_CHECK_LAUNCH();
+    return 0;
+  }
+  if (p.bias) {   // separate instantiation: the score-bias loads must not touch the hot no-bias instruction stream
+    if (p.causal) {
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<true, NW, true>, lds, a0, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW, true>), grid, dim3(NW * 64), lds, stream, q);
+    } else {
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, true>, lds, a1, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
+    }
   } else {
-    if (p.causal) hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW>), grid, dim3(NW * 64), lds, stream, q);
-    else hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW>), grid, dim3(NW * 64), lds, stream, q);
+    if (p.causal) {
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<true, NW>, lds, a2, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW>), grid, dim3(NW * 64), lds, stream, q);
+    } else {
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW>, lds, a3, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW>), grid, dim3(NW * 64), lds, stream, q);
+    }
   }
   TD_CHECK_LAUNCH();
   return 0;

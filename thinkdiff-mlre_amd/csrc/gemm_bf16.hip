@@ -17,6 +17,8 @@
 //    stores are full 128-B lines per row, with no LDS round trip.
 //  * blockIdx -> tile mapping is XCD-aware (bijective remap + grouped M ordering) so the 32
 //    tiles resident on one XCD share A/W panels through that XCD's L2.
+#include <atomic>
+
 #include "td_common.h"
 #include "td_kernels.h"
 
@@ -34,46 +36,82 @@ __device__ __forceinline__ float apply_act(float x) {
   else return x;
 }
 
-// Lane owns NV = 4*WN contiguous output columns [nbeg, nbeg+NV) of rows mbeg + 16*i.
-// Rounding points follow the reference's bf16 torch pipeline: Linear output, activation,
-// gate multiply and residual add each round to bf16.
+// Epilogue.  A lane owns NV = 4*WN contiguous output columns [nbeg, nbeg+NV) of rows mbeg + 16*i.
+// Rounding points follow the reference's bf16 torch pipeline: Linear output, activation, gate multiply and residual add
+// each round to bf16.
+// Every global access goes through a buffer descriptor that carries the true extent of its tensor: rows >= M, a null
+// bias / residual and column chunks past N are range-checked by the hardware (loads return 0, stores are dropped), so the
+// epilogue is straight-line code -- no per-access exec-mask branch, no 64-bit address arithmetic.  (The first form, with an
+// `if (row ok && column ok)` around each access, compiled to ~20 k instructions with 24 spilled VGPRs in the 256x256 kernel;
+// at one workgroup per CU the epilogue is dead time for the matrix pipe.)
 // the problem a block works on (grouped launches carry two; see TdGemmParams)
 struct ProbView {
   const bf16_t* bias; const bf16_t* gate; const bf16_t* res; bf16_t* C; int M;
 };
 
-template <int WM, int WN, int ACT, int MODE>   // MODE 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
-__device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second) {
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;   // beyond any descriptor range (operands are < 4 GiB - 64 KiB, checked on the host)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, p ? bytes : 0u, 0x00020000);
+}
+
+// `act` and `mode` are block-uniform run-time values: ONE body, with scalar branches around the optional stages of a row.
+// (One instantiation per activation, selected by a switch in front, made the compiler hoist the shared `acc + bias` of all
+// WM rows above the switch: 128 extra live values and a spilling kernel.)
+template <int WM, int WN>   // mode 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
+__device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second,
+                                         const int act, const int mode) {
   constexpr int NV = 4 * WN;
+  constexpr int CH = (NV % 8 == 0) ? 8 : 4;          // columns per access: 16-byte accesses when the lane's span allows
+  constexpr int NCH = NV / CH;
   bf16_t* Cout = second ? pp.C2 : p.C;
   const int ldo = second ? pp.ldc2 : pp.ldc;
   const int ncol = second ? nbeg - pp.n_split : nbeg;
-  const bool use_gate = p.gate != nullptr, use_res = p.res != nullptr, has_bias = p.bias != nullptr;
+  const int ncols_out = second ? pp.N - pp.n_split : (pp.C2 ? pp.n_split : pp.N);
+  const bool use_res = p.res != nullptr;
 
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cout, (unsigned)(((long long)(p.M - 1) * ldo + ncols_out) * 2));
+  const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * pp.ldr + pp.N) * 2));
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.bias, (unsigned)pp.N * 2u);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(p.gate, (unsigned)pp.N * 2u);
+
+  // per-column operands of the lane's NV columns (a null bias / gate reads as zeros; mode 1 always has a gate)
   float bias[NV], gate[NV];
+  unsigned coff[NCH];            // byte offset of chunk c inside an output row
+  bool cok[NCH];                 // chunk c lies inside N (N % 8 == 0: a chunk is entirely inside or entirely outside)
 #pragma unroll
-  for (int c = 0; c < NV; c += 4) {
-    const bool inr = nbeg + c + 4 <= pp.N;
-    u32x2_t b = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
-    if (p.bias && inr) b = *(const u32x2_t*)(p.bias + nbeg + c);
-    if (use_gate && inr) g = *(const u32x2_t*)(p.gate + nbeg + c);
-    bias[c] = bf_lo(b[0]); bias[c + 1] = bf_hi(b[0]); bias[c + 2] = bf_lo(b[1]); bias[c + 3] = bf_hi(b[1]);
-    gate[c] = bf_lo(g[0]); gate[c + 1] = bf_hi(g[0]); gate[c + 2] = bf_lo(g[1]); gate[c + 3] = bf_hi(g[1]);
+  for (int c = 0; c < NCH; ++c) {
+    const bool inr = nbeg + c * CH + CH <= pp.N;
+    cok[c] = inr;
+    coff[c] = (unsigned)(ncol + c * CH) * 2u;
+    if constexpr (CH == 8) {
+      const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(nbeg + c * CH) * 2u, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { bias[c * 8 + 2 * k] = bf_lo(b[k]); bias[c * 8 + 2 * k + 1] = bf_hi(b[k]); }
+      {
+        const u32x4_t g = __builtin_amdgcn_raw_buffer_load_b128(rsG, (unsigned)(nbeg + c * CH) * 2u, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { gate[c * 8 + 2 * k] = bf_lo(g[k]); gate[c * 8 + 2 * k + 1] = bf_hi(g[k]); }
+      }
+    } else {
+      const u32x2_t b = __builtin_amdgcn_raw_buffer_load_b64(rsB, (unsigned)(nbeg + c * CH) * 2u, 0, 0);
+      bias[c * 4] = bf_lo(b[0]); bias[c * 4 + 1] = bf_hi(b[0]); bias[c * 4 + 2] = bf_lo(b[1]); bias[c * 4 + 3] = bf_hi(b[1]);
+      {
+        const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(rsG, (unsigned)(nbeg + c * CH) * 2u, 0, 0);
+        gate[c * 4] = bf_lo(g[0]); gate[c * 4 + 1] = bf_hi(g[0]); gate[c * 4 + 2] = bf_lo(g[1]); gate[c * 4 + 3] = bf_hi(g[1]);
+      }
+    }
   }
 
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
+  auto row = [&](const int i) {
     const int m = mbeg + i * 16;
-    const bool mok = m < p.M;
     float v[NV];
 #pragma unroll
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[j][i][r];
     // Rounding points of the bf16 torch graph: the Linear output rounds before any following op, and so does every
-    // following op; when nothing follows, the final pack is that rounding.  The stage selection is block-uniform
-    // and sits OUTSIDE the per-value loops (a per-value runtime select tripled the epilogue's VALU count, and the
-    // epilogue is dead time for the matrix pipe at one workgroup per CU).
+    // following op; when nothing follows, the final pack is that rounding.
     auto round_all = [&]() {
 #pragma unroll
       for (int c = 0; c < NV; c += 2) {
@@ -82,58 +120,90 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
         v[c + 1] = bf_hi(u);
       }
     };
-    if (has_bias) {
 #pragma unroll
-      for (int c = 0; c < NV; ++c) v[c] += bias[c];
-    }
-    if constexpr (ACT != TD_ACT_NONE) {
+    for (int c = 0; c < NV; ++c) v[c] += bias[c];
+    if (act != TD_ACT_NONE) {
       round_all();
+      switch (act) {
+        case TD_ACT_GELU_TANH:
 #pragma unroll
-      for (int c = 0; c < NV; ++c) v[c] = apply_act<ACT>(v[c]);
+          for (int c = 0; c < NV; ++c) v[c] = apply_act<TD_ACT_GELU_TANH>(v[c]);
+          break;
+        case TD_ACT_GELU_ERF:
+#pragma unroll
+          for (int c = 0; c < NV; ++c) v[c] = apply_act<TD_ACT_GELU_ERF>(v[c]);
+          break;
+        case TD_ACT_SILU:
+#pragma unroll
+          for (int c = 0; c < NV; ++c) v[c] = apply_act<TD_ACT_SILU>(v[c]);
+          break;
+        default:
+#pragma unroll
+          for (int c = 0; c < NV; ++c) v[c] = apply_act<TD_ACT_QUICK_GELU>(v[c]);
+          break;
+      }
     }
-    if constexpr (MODE == 1) {
+    if (mode == 1) {
       round_all();
 #pragma unroll
       for (int c = 0; c < NV; ++c) v[c] *= gate[c];
     }
-    if constexpr (MODE != 0) {
-      if (use_res && mok) {
+    {
+      if (mode != 0 && use_res) {            // block-uniform
         round_all();
-        const bf16_t* rp = p.res + (size_t)m * pp.ldr + nbeg;
+        const unsigned roff = (unsigned)m * (unsigned)pp.ldr * 2u + (unsigned)nbeg * 2u;
 #pragma unroll
-        for (int c = 0; c < NV; c += 4) {
-          if (nbeg + c + 4 <= pp.N) {
-            const u32x2_t rv = *(const u32x2_t*)(rp + c);
-            v[c] += bf_lo(rv[0]); v[c + 1] += bf_hi(rv[0]); v[c + 2] += bf_lo(rv[1]); v[c + 3] += bf_hi(rv[1]);
+        for (int c = 0; c < NCH; ++c) {
+          if constexpr (CH == 8) {
+            const u32x4_t rv = __builtin_amdgcn_raw_buffer_load_b128(rsR, roff + c * 16, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[c * 8 + 2 * k] += bf_lo(rv[k]); v[c * 8 + 2 * k + 1] += bf_hi(rv[k]); }
+          } else {
+            const u32x2_t rv = __builtin_amdgcn_raw_buffer_load_b64(rsR, roff + c * 8, 0, 0);
+            v[c * 4] += bf_lo(rv[0]); v[c * 4 + 1] += bf_hi(rv[0]); v[c * 4 + 2] += bf_lo(rv[1]); v[c * 4 + 3] += bf_hi(rv[1]);
           }
         }
       }
     }
-    if (pp.out_f32) {   // raw fp32 rows (attention scores of the VAE mid block): no bf16 rounding of the sum
-      float* fp = (float*)Cout + (size_t)m * ldo + ncol;
+    const unsigned ooff = (unsigned)m * (unsigned)ldo * 2u;
 #pragma unroll
-      for (int c = 0; c < NV; c += 4) {
-        const f32x4_t o4 = {acc[c / 4][i][0] + bias[c], acc[c / 4][i][1] + bias[c + 1], acc[c / 4][i][2] + bias[c + 2], acc[c / 4][i][3] + bias[c + 3]};
-        if (mok && nbeg + c + 4 <= pp.N) *(f32x4_t*)(fp + c) = o4;
-      }
-      continue;
-    }
-    bf16_t* cp = Cout + (size_t)m * ldo + ncol;
-    if constexpr (NV % 8 == 0) {
-#pragma unroll
-      for (int c = 0; c < NV; c += 8) {
+    for (int c = 0; c < NCH; ++c) {
+      if constexpr (CH == 8) {
         u32x4_t o;
-        o[0] = pack_bf2(v[c], v[c + 1]); o[1] = pack_bf2(v[c + 2], v[c + 3]);
-        o[2] = pack_bf2(v[c + 4], v[c + 5]); o[3] = pack_bf2(v[c + 6], v[c + 7]);
-        if (mok && nbeg + c + 8 <= pp.N) *(u32x4_t*)(cp + c) = o;
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NV; c += 4) {
+        o[0] = pack_bf2(v[c * 8], v[c * 8 + 1]); o[1] = pack_bf2(v[c * 8 + 2], v[c * 8 + 3]);
+        o[2] = pack_bf2(v[c * 8 + 4], v[c * 8 + 5]); o[3] = pack_bf2(v[c * 8 + 6], v[c * 8 + 7]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsC, cok[c] ? ooff + coff[c] : OOB_OFFSET, 0, 0);   // (a sum with OOB_OFFSET would wrap)
+      } else {
         u32x2_t o;
-        o[0] = pack_bf2(v[c], v[c + 1]); o[1] = pack_bf2(v[c + 2], v[c + 3]);
-        if (mok && nbeg + c + 4 <= pp.N) *(u32x2_t*)(cp + c) = o;
+        o[0] = pack_bf2(v[c * 4], v[c * 4 + 1]); o[1] = pack_bf2(v[c * 4 + 2], v[c * 4 + 3]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, rsC, cok[c] ? ooff + coff[c] : OOB_OFFSET, 0, 0);
       }
+    }
+  };
+  // two halves: the scheduler may hoist the residual loads of one half ahead of its arithmetic, not those of all WM rows
+  // (which is what ran the 256x256 kernel out of registers)
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    row(i);
+    if (WM >= 4 && i == WM / 2 - 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// raw fp32 rows (attention scores of the VAE mid block): acc + bias, no bf16 rounding, no activation / gate / residual
+template <int WM, int WN>
+__device__ __forceinline__ void epilogue_f32(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg) {
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C, (unsigned)(((long long)(p.M - 1) * pp.ldc + pp.N) * 4));
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.bias, (unsigned)pp.N * 2u);
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const u32x2_t b = __builtin_amdgcn_raw_buffer_load_b64(rsB, (unsigned)(nbeg + j * 4) * 2u, 0, 0);
+    const f32x4_t b4 = {bf_lo(b[0]), bf_hi(b[0]), bf_lo(b[1]), bf_hi(b[1])};
+    const bool cok = nbeg + j * 4 + 4 <= pp.N;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const f32x4_t o4 = acc[j][i] + b4;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o4), rsC,
+                                             cok ? (unsigned)(mbeg + i * 16) * (unsigned)pp.ldc * 4u + (unsigned)(nbeg + j * 4) * 4u : OOB_OFFSET, 0, 0);
     }
   }
 }
@@ -145,7 +215,7 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
 // v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 MFMA rate).  The k <-> (lane, byte) map of the
 // instruction does not matter: both operands are read with the same map and the contraction sums over all k.
 // Dequantisation is per output row (a_scale[m]) x per output column (w_scale[n]) on the fp32 accumulators.
-template <int WM, int WN, int VARIANT = 2, bool CONV = false, bool FP8 = false>
+template <int WM, int WN, bool CONV = false, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   constexpr int BM = 32 * WM, BN = 64 * WN;
@@ -154,7 +224,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   constexpr int SA = (GA + 7) / 8, SW = (GW + 7) / 8;  // staging instructions per wave
   constexpr int NV = 4 * WN;                          // contiguous output columns per lane
   constexpr unsigned ESZ = FP8 ? 1u : 2u;             // operand element size in bytes
-  static_assert(!FP8 || (VARIANT == 2 && !CONV), "the fp8 path exists for the shipped pipeline only");
+  static_assert(!FP8 || !CONV, "no fp8 convolution");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -253,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     const unsigned off = ((unsigned)(sy * win + sx) * (unsigned)p.conv_Cin + (unsigned)c0) * 2u + schunk;
     return ok ? off : 0xFFFFFF00u;
   };
-  // LDS: [A buf 0 | A buf 1 | W buf 0 | W buf 1 | W buf 2]; the third W buffer exists for VARIANT 2 only
+  // LDS: [A buf 0 | A buf 1 | W buf 0 | W buf 1 | W buf 2]
   constexpr int W_REGION = 2 * A_BYTES;
   auto stage_one = [&](int s, int abuf, int wbuf, int kt) {
     if (s < SA) {
@@ -345,63 +415,31 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
       }
     }
   } else
-  if constexpr (VARIANT == 0) {
-    // baseline structure kept for in-process A/B runs: stage the next tile up front, then all fragment
-    // reads of a k-step followed by its MFMAs (compiler-scheduled)
-    for (int t = 0; t < nt; ++t) {
-      __syncthreads();
-      if (t + 1 < nt) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) stage_one(s, (t + 1) & 1, (t + 1) & 1, t + 1);
-      }
-      const char* abase = smem + (t & 1) * A_BYTES;
-      const char* wbase = smem + W_REGION + (t & 1) * W_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int fo = foff0 ^ (ks << 6);
-        bf16x8_t wf[WN], af[WM];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(wbase + woff + j * 16 * ROW_BYTES + fo);
-#pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8_t*)(abase + aoff + i * 16 * ROW_BYTES + fo);
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-      }
-    }
-  } else {
+  {
   // Main loop, one barrier per k-tile.  Inside a tile every instruction kind is spread through the MFMA
   // stream (pinned with sched_group_barrier, hipcc otherwise clusters them):
   //  * the NS LDS-DMA instructions of tile t+1 ride on the first m-tiles (their ~60-cycle issue cost hides
   //    behind MFMAs instead of fronting the tile while the matrix pipe idles);
   //  * the WN W-fragments of a k-step stay resident, A-fragments are read one m-tile ahead of the MFMAs
   //    that consume them, the next k-step's W-fragments behind the last m-tiles.
-  //  * VARIANT 2: the W tile (the operand that streams cold from HBM: every layer has its own weights)
+  //  * the W tile (the operand that streams cold from HBM: every layer has its own weights)
   //    is prefetched TWO k-tiles ahead into a 3-deep W ring, the A tile (L2-resident activations) one
   //    ahead.  A DMAs are issued before the W DMAs of an iteration, so the counted `s_waitcnt vmcnt(SW)`
   //    at the barrier retires tile t+1's operands and leaves the W(t+2) transfers in flight across it.
-  if constexpr (VARIANT == 2) {
 #pragma unroll
-    for (int s = SA; s < NS; ++s) stage_one(s, 0, 1, min(1, nt - 1));
-  }
+  for (int s = SA; s < NS; ++s) stage_one(s, 0, 1, min(1, nt - 1));
   int wcur = 0;
   for (int t = 0; t < nt; ++t) {
-    if constexpr (VARIANT == 2) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
-      __builtin_amdgcn_s_barrier();
-    } else {
-      __syncthreads();  // s_waitcnt vmcnt(0) + barrier: tile t landed, buffer (t+1)&1 free
-    }
-    const int wslot = VARIANT == 2 ? wcur : (t & 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const int wslot = wcur;
     const char* wb = smem + W_REGION + wslot * W_BYTES + woff;
     const char* ab = smem + (t & 1) * A_BYTES + aoff;
     // tiles past the last are harmless re-loads of the last one (keeps the loop body branch-free)
     const int kt_a = min(t + 1, nt - 1);
-    const int kt_w = VARIANT == 2 ? min(t + 2, nt - 1) : kt_a;
+    const int kt_w = min(t + 2, nt - 1);
     const int abuf_next = (t + 1) & 1;
-    const int wbuf_next = VARIANT == 2 ? (wcur == 0 ? 2 : wcur - 1) : abuf_next;   // (wcur + 2) % 3
+    const int wbuf_next = wcur == 0 ? 2 : wcur - 1;   // (wcur + 2) % 3
     wcur = wcur == 2 ? 0 : wcur + 1;
     bf16x8_t wf[2][WN], af[2];
 #pragma unroll
@@ -469,60 +507,56 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   const int act = second ? p.act2 : p.act;
   const int mbeg = m0 + wr * 16 * WM + frow;
   if constexpr (FP8) {   // y = (sum q_a q_w) * a_scale[row] * w_scale[col]
-    const float* sa = second_prob ? p.g_a_scale : p.a_scale;
-    const float* sw = second_prob ? p.g_w_scale : p.w_scale;
+    // range-checked loads: rows >= M / columns >= N read a zero scale (their outputs are dropped anyway)
+    const __amdgpu_buffer_rsrc_t rsSa = make_rsrc(second_prob ? p.g_a_scale : p.a_scale, (unsigned)pv.M * 4u);
+    const __amdgpu_buffer_rsrc_t rsSw = make_rsrc(second_prob ? p.g_w_scale : p.w_scale, (unsigned)p.N * 4u);
     float swv[NV];
 #pragma unroll
     for (int c = 0; c < NV; c += 4) {
-      f32x4_t w4 = {0.f, 0.f, 0.f, 0.f};
-      if (nbeg + c + 4 <= p.N) w4 = *(const f32x4_t*)(sw + nbeg + c);
+      const f32x4_t w4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsSw, (unsigned)(nbeg + c) * 4u, 0, 0));
       swv[c] = w4[0]; swv[c + 1] = w4[1]; swv[c + 2] = w4[2]; swv[c + 3] = w4[3];
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      const int m = mbeg + i * 16;
-      const float sr = m < pv.M ? sa[m] : 0.f;
+      const float sr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsSa, (unsigned)(mbeg + i * 16) * 4u, 0, 0));
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[j][i][r] *= sr * swv[j * 4 + r];
     }
   }
-  // one instantiation per activation keeps every acc[][] index static (runtime-indexed
-  // accumulators would be demoted to scratch)
-  // (an activation followed by a gate / residual does not occur on this path: act wins, as before the split)
-  const int mode = act != TD_ACT_NONE ? 0 : (pv.gate ? 1 : (pv.res ? 2 : 0));
-  if (mode == 1) epilogue<WM, WN, TD_ACT_NONE, 1>(p, pv, acc, mbeg, nbeg, second);
-  else if (mode == 2) epilogue<WM, WN, TD_ACT_NONE, 2>(p, pv, acc, mbeg, nbeg, second);
-  else switch (act) {
-    case TD_ACT_GELU_TANH: epilogue<WM, WN, TD_ACT_GELU_TANH, 0>(p, pv, acc, mbeg, nbeg, second); break;
-    case TD_ACT_GELU_ERF: epilogue<WM, WN, TD_ACT_GELU_ERF, 0>(p, pv, acc, mbeg, nbeg, second); break;
-    case TD_ACT_SILU: epilogue<WM, WN, TD_ACT_SILU, 0>(p, pv, acc, mbeg, nbeg, second); break;
-    case TD_ACT_QUICK_GELU: epilogue<WM, WN, TD_ACT_QUICK_GELU, 0>(p, pv, acc, mbeg, nbeg, second); break;
-    default: epilogue<WM, WN, TD_ACT_NONE, 0>(p, pv, acc, mbeg, nbeg, second); break;
+  // (an activation followed by a gate / residual does not occur on this path: act wins)
+  if (p.out_f32) {
+    epilogue_f32<WM, WN>(p, pv, acc, mbeg, nbeg);
+    return;
   }
+  const int mode = act != TD_ACT_NONE ? 0 : (pv.gate ? 1 : (pv.res ? 2 : 0));
+  epilogue<WM, WN>(p, pv, acc, mbeg, nbeg, second, act, mode);
 #endif
 }
 
 namespace {
 
-template <int WM, int WN, int VARIANT = 2, bool CONV = false, bool FP8 = false>
+template <int WM, int WN, bool CONV = false, bool FP8 = false>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
-  constexpr int LDS = (2 * BM + (VARIANT == 2 ? 3 : 2) * BN) * ROW_BYTES;
+  constexpr int LDS = (2 * BM + 3 * BN) * ROW_BYTES;
   TdGemmParams p = p0;
   p.tiles_m0 = (p.M + BM - 1) / BM;
   p.tiles_m = p.tiles_m0 + (p.g_M > 0 ? (p.g_M + BM - 1) / BM : 0);
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV, FP8>,
+  // the dynamic-LDS limit is a per-device function attribute: set it once per device (a process may drive several)
+  static std::atomic<unsigned long long> attr_done{0ull};
+  int dev = 0;
+  TD_CHECK_HIP(hipGetDevice(&dev));
+  if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
+    attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, VARIANT, CONV, FP8>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -550,8 +584,13 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.K % (128 / esz) == 0, "td_gemm: K=%d must be a multiple of %d", p.K, 128 / esz);
   TD_CHECK_ARG(p.N % 8 == 0, "td_gemm: N=%d must be a multiple of 8", p.N);
   TD_CHECK_ARG((p.conv_H > 0 || p.lda >= p.K) && p.ldc >= (p.C2 ? p.n_split : p.N), "td_gemm: bad leading dimensions");
-  TD_CHECK_ARG(((long long)(p.M + 255) * p.lda + p.K) * esz < (1ll << 32) && (long long)(p.N + 255) * p.K * esz < (1ll << 32),
+  // 32-bit descriptor offsets: rows of the last tile may run up to one tile (<= 288 rows) past M / N before the range check drops them
+  constexpr long long LIM = (1ll << 32) - (1ll << 16);
+  TD_CHECK_ARG(((long long)(p.M + 288) * p.lda + p.K) * esz < LIM && (long long)(p.N + 288) * p.K * esz < LIM,
                "td_gemm: operand exceeds the 4 GiB buffer-descriptor range");
+  TD_CHECK_ARG((long long)(p.M + 288) * p.ldc * (p.out_f32 ? 4 : 2) < LIM && (long long)(p.M + 288) * (p.C2 ? p.ldc2 : 0) * 2 < LIM &&
+               (long long)(p.M + 288) * (p.res ? p.ldr : 0) * 2 < LIM && (long long)(p.g_M + 288) * p.ldc * 2 < LIM,
+               "td_gemm: output / residual exceeds the 4 GiB buffer-descriptor range");
   TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C) % 16 == 0 && p.lda % (16 / esz) == 0 && p.ldc % 8 == 0,
                "td_gemm: pointers / leading dimensions must be 16-byte aligned");
   if (p.res) TD_CHECK_ARG(p.ldr % 4 == 0, "td_gemm: ldr must be a multiple of 4");
@@ -565,7 +604,7 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
                  "td_gemm(conv): need Cin %% 64 == 0, K == 9 Cin, M == H W (got Cin=%d K=%d M=%d H=%d W=%d)", p.conv_Cin, p.K, p.M, p.conv_H, p.conv_W);
     TD_CHECK_ARG(p.conv_up == 0 || (p.conv_H % 2 == 0 && p.conv_W % 2 == 0), "td_gemm(conv): upsampled output dims must be even");
     // output-channel tile: 64, 128 (the 128-channel 1024^2 / 512^2 layers of the VAE: a 256-wide tile would be half empty) or 256
-    return p.N <= 64 ? launch_cfg<8, 1, 2, true>(p, stream) : p.N <= 128 ? launch_cfg<8, 2, 2, true>(p, stream) : launch_cfg<8, 4, 2, true>(p, stream);
+    return p.N <= 64 ? launch_cfg<8, 1, true>(p, stream) : p.N <= 128 ? launch_cfg<8, 2, true>(p, stream) : launch_cfg<8, 4, true>(p, stream);
   }
   // M <= 16 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode of up to 16 sequences, embedders, lm_head)
   if (p.glu_I) {
@@ -578,19 +617,15 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,
                  "td_gemm(fp8): row / column dequantisation scales are required; no conv / fp32-out form");
     switch (cfg) {
-      case 2: return launch_cfg<1, 4, 2, false, true>(p, stream);
-      case 3: return launch_cfg<9, 3, 2, false, true>(p, stream);
-      default: return launch_cfg<8, 4, 2, false, true>(p, stream);
+      case 2: return launch_cfg<1, 4, false, true>(p, stream);
+      case 3: return launch_cfg<9, 3, false, true>(p, stream);
+      default: return launch_cfg<8, 4, false, true>(p, stream);
     }
   }
-  switch (cfg) {   // 0-3: shipped pipeline (VARIANT 2); 1x / 3x: earlier loop structures kept for in-process A/B
-    case 1: return launch_cfg<8, 1, 2>(p, stream);
-    case 2: return launch_cfg<1, 4, 2>(p, stream);
-    case 3: return launch_cfg<9, 3, 2>(p, stream);
-    case 10: return launch_cfg<8, 4, 0>(p, stream);
-    case 13: return launch_cfg<9, 3, 0>(p, stream);
-    case 30: return launch_cfg<8, 4, 1>(p, stream);
-    case 33: return launch_cfg<9, 3, 1>(p, stream);
-    default: return launch_cfg<8, 4, 2>(p, stream);
+  switch (cfg) {
+    case 1: return launch_cfg<8, 1>(p, stream);
+    case 2: return launch_cfg<1, 4>(p, stream);
+    case 3: return launch_cfg<9, 3>(p, stream);
+    default: return launch_cfg<8, 4>(p, stream);
   }
 }

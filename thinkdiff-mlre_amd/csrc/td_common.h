@@ -30,6 +30,10 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   p[1] = (__bf16)hi;
   return __builtin_bit_cast(unsigned, p);
 }
+// Bit views of a scalar, taken BY VALUE: `__builtin_bit_cast(unsigned, vec[i])` on an ext_vector element reads element 0
+// whatever `i` is (hipcc / clang 22: the element expression is not an addressable lvalue), silently.
+__device__ __forceinline__ unsigned as_u32(float f) { return __builtin_bit_cast(unsigned, f); }
+__device__ __forceinline__ float as_f32(unsigned u) { return __builtin_bit_cast(float, u); }
 // round an f32 through bf16 (emulates one torch bf16 op boundary of the reference pipeline)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }

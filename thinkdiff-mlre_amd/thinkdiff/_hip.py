@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libthinkdiff_hip.so")
+# TD_HIP_LIB: another build of the same library (A/B timing of two builds on one box); never a different implementation
+LIB_PATH = os.environ.get("TD_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libthinkdiff_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 
@@ -111,6 +112,8 @@ def _declare(L):
         "td_sample_top_p_bf16": [vp, i64, i32, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, vp, vp],
     }
     for name, args in sig.items():
+        if os.environ.get("TD_HIP_LIB") and not hasattr(L, name):
+            continue          # an older build under A/B timing may predate an entry point; the shipped library must export all
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = ctypes.c_int

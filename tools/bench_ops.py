@@ -89,6 +89,37 @@ def bench_gemmfp8():
         del pool, qpool
 
 
+def bench_gemmepi():
+    """The six block GEMMs of a FLUX step with their real epilogues (bias / GELU / gate + residual / split output), cold weights."""
+    S = 4289
+    cases = [("qkv   bias", 9216, 3072, "bias"), ("out   gate+res", 3072, 3072, "gr"), ("ff1   gelu", 12288, 3072, "gelu"),
+             ("ff2   gate+res", 3072, 12288, "gr"), ("W1    split+gelu", 21504, 3072, "split"), ("W2    gate+res", 3072, 15360, "gr")]
+    tot = 0.0
+    for name, N, K, kind in cases:
+        x = torch.randn(S, K, device="cuda").bfloat16()
+        npool = max(2, int(1.2e9 // (N * K * 2)))
+        pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(npool)]
+        b = torch.randn(N, device="cuda").bfloat16()
+        g = torch.randn(N, device="cuda").bfloat16()
+        y = torch.empty(S, N, device="cuda", dtype=torch.bfloat16)
+        r = torch.randn(S, N, device="cuda").bfloat16() if kind == "gr" else None
+        y0 = torch.empty(S, 9216, device="cuda", dtype=torch.bfloat16) if kind == "split" else None
+        y1 = torch.empty(S, 15360, device="cuda", dtype=torch.bfloat16)[:, 3072:] if kind == "split" else None
+        st = {"i": 0}
+        def f():
+            st["i"] = (st["i"] + 1) % npool
+            w = pool[st["i"]]
+            if kind == "bias": _hip.linear(x, w, b, out=y)
+            elif kind == "gelu": _hip.linear(x, w, b, act=_hip.ACT_GELU_TANH, out=y)
+            elif kind == "gr": _hip.linear(x, w, b, gate=g, res=r, out=r)
+            else: _hip.linear_split(x, w, b, y0, _hip.ACT_NONE, y1, _hip.ACT_GELU_TANH, 9216)
+        best = min(timeit(f, iters=10, warmup=2) for _ in range(4))
+        tot += best
+        print(f"{name:18s} N={N:5d} K={K:5d}: {best*1e3:7.1f} us  {2.0*S*N*K/best/1e9:7.1f} TF/s", flush=True)
+        del pool
+    print(f"sum {tot:.3f} ms")
+
+
 def bench_gemmsmall():
     """Mid-M Linears (encoders, towers, short prefills): 256x256 tiles (cfg 0) vs 256x64 tiles (cfg 1) vs 32x256 (cfg 2, M <= 32)."""
     for M, N, K in [(128, 24576, 4096), (128, 20480, 4096), (128, 4096, 10240), (300, 4608, 3584), (300, 37888, 3584), (300, 3584, 18944),
@@ -195,24 +226,26 @@ def bench_gemmcold():
 
 
 def bench_attn():
-    for S, H in [(4289, 24), (4224, 24), (4096, 24), (8192, 24)]:
-        qkv = torch.randn(1, S, 3 * H * 128, device="cuda").bfloat16()
-        out = torch.empty(1, S, H * 128, device="cuda", dtype=torch.bfloat16)
-        q, k, v = qkv[:, :, :H * 128], qkv[:, :, H * 128:2 * H * 128], qkv[:, :, 2 * H * 128:]
-        best = {0: 1e9, 1: 1e9}
-        for _ in range(4):
-            for var in (0, 1):
+    """Joint attention, in-process interleaved A/B of the kernel structures (variant 0 shipped / 1 one workgroup per item /
+    2 persistent without the XCD range order), cold inputs (pool cycling)."""
+    names = {0: "shipped", 1: "wg-per-item", 2: "streamk-noremap"}
+    for S, H in [(4289, 24), (4354, 24), (4224, 24), (1280, 24)]:
+        W = H * 128
+        pool = [torch.randn(1, S, 3 * W, device="cuda").bfloat16() for _ in range(6)]
+        out = torch.empty(1, S, W, device="cuda", dtype=torch.bfloat16)
+        st = {"i": 0}
+        def f():
+            st["i"] = (st["i"] + 1) % len(pool)
+            q = pool[st["i"]]
+            _hip.attention(q[:, :, :W], q[:, :, W:2 * W], q[:, :, 2 * W:], out, H, H)
+        best = {v: 1e9 for v in names}
+        for _ in range(5):
+            for var in names:
                 _hip.lib().td_attention_set_variant(var)
-                best[var] = min(best[var], timeit(lambda: _hip.attention(q, k, v, out, H, H), iters=10, warmup=2))
+                best[var] = min(best[var], timeit(f, iters=10, warmup=2))
         _hip.lib().td_attention_set_variant(0)
-        ms = best[0]
         fl = 4.0 * S * S * H * 128
-        print(f"   lean {fl/best[0]/1e9:7.1f} TF/s   lockstep {fl/best[1]/1e9:7.1f} TF/s")
-        qh = q.reshape(1, S, H, 128).transpose(1, 2)
-        kh = k.reshape(1, S, H, 128).transpose(1, 2)
-        vh = v.reshape(1, S, H, 128).transpose(1, 2)
-        ref_ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh))
-        print(f"attn S={S} H={H}: {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s   (torch SDPA: {ref_ms:8.3f} ms {fl/ref_ms/1e9:7.1f} TF/s)", flush=True)
+        print(f"attn S={S} H={H}: " + "   ".join(f"{names[v]} {best[v]*1e3:6.1f} us {fl/best[v]/1e9:6.0f} TF/s" for v in names), flush=True)
 
 
 def bench_flux():
