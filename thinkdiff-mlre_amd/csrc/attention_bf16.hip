@@ -21,6 +21,7 @@
 #include <atomic>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "td_common.h"
 #include "td_kernels.h"
@@ -319,37 +320,45 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 // ---------------------------------------------------------------------------------------------
 // Stream-K form of the kernel above for joint (non-causal) attention: the launch is ONE round of persistent workgroups.
 //
-// FLUX at 1024^2: 17 query tiles x 24 heads = 408 workgroups of 67 KV tiles each on 256 CUs -- two rounds, the second 59 %
-// empty (20 % of the kernel's time).  Here the 408 x 67 (item, KV tile) iterations are cut into G equal contiguous ranges,
-// one per workgroup, G = number of CUs.  A range starts inside an item and ends inside another, so a workgroup runs
+// FLUX at 1024^2: 17 query tiles x 24 heads = 408 workgroups of 68 KV tiles each on 256 CUs -- two rounds, the second 59 %
+// empty.  Here the 408 x 68 (item, KV tile) iterations are cut into G equal contiguous ranges, one per workgroup, G = number
+// of CUs.  A range starts inside an item and ends inside another, so a workgroup runs
 //   [tail part of item a : KV tiles kb..nt) ] [whole items ...] [head part of item z : KV tiles 0..ke) ]
-// and every item is split over at most two workgroups (a range is longer than an item).  The workgroup that owns an
-// item's TAIL part meets it first thing in its life and hands its un-normalised state (O accumulators, row max, row sum:
-// 68 floats per lane) to the owner of the HEAD part through a workspace slot; that owner reaches the item last, merges the
-// two online-softmax states exactly as two KV tiles are merged inside the loop, normalises and stores.  The hand-off is the
-// placement-independent recipe (guide 6, Guideline 16 R1): write-through (sc1) 16-byte stores, every storing wave drains
-// (s_waitcnt vmcnt(0)), workgroup barrier, one lane stores the flag (agent scope); the consumer polls that one word relaxed,
-// then ONE agent-scope acquire, s_waitcnt, barrier, plain loads.  The consumer clears the flag; the launcher zeroes the flag
-// block when the workspace is created.  Producer work is the FIRST thing a workgroup does and the wait the LAST, so with every
-// workgroup resident (G <= CUs) the wait is normally already satisfied; the spin is bounded all the same and a time-out is
-// recorded in the workspace header for the host (td_attn_launch refuses further launches once it is set).
+// and every item is split over at most two workgroups (a range is longer than an item).  The two owners of a split item
+// combine their un-normalised online-softmax states (O accumulators, row max, row sum: 68 floats per lane) exactly as two KV
+// tiles are combined inside the loop, and whoever arrives SECOND does it -- nobody ever waits:
+//   * the owner of the TAIL part (it meets the item first thing in its life) writes its state to slot T[j] of the boundary j
+//     between the two ranges and draws a ticket from cnt[j]; ticket 0: done, ticket 1: the other side has already left its
+//     state in H[j] -- read it, combine, normalise, store;
+//   * the owner of the HEAD part (it meets the item last) first looks at cnt[j]: 1 (the normal case) -- read T[j], combine with
+//     the state it holds in registers, normalise, store; 0 -- leave its own state in H[j] and draw a ticket, and if that comes
+//     back 1 after all, finish as above from registers.
+// With no wait there is no forward-progress assumption: any number of these launches may share the chip with anything else,
+// in any dispatch order (a spin version deadlocks when a consumer's producer is not resident).  The hand-off is the
+// placement-independent recipe of the guide (6, Guideline 16 R1 with a counter as the flag): write-through (sc1) 16-byte
+// stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE agent-scope atomic add; the reader's side is
+// ONE agent-scope acquire after the atomic that told it, s_waitcnt, barrier, plain loads.  The finisher zeroes cnt[j]; the
+// workspace (one per engine context / stream: concurrent launches must not share it) is zeroed when it is created.
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int SK_SLOT_FLOATS = 8 * 64 * 68;          // per workgroup: 8 waves x 64 lanes x (64 O + m + l + 2 pad) floats
-constexpr int SK_HEADER_WORDS = 1024;                 // [0]: time-out word, [16 + r]: flag of logical range r
-struct SkWorkspace { float* slots; unsigned* header; int ranges; };
+constexpr int SK_SLOT_FLOATS = 8 * 64 * 68;          // per boundary and side: 8 waves x 64 lanes x (64 O + m + l + 2 pad) floats
+constexpr int SK_HEADER_BYTES = 4096;                 // cnt[j] at word 16 + j
+constexpr int SK_MAX_RANGES = SK_HEADER_BYTES / 4 - 16;
+// workspace = [header | T slots: ranges x SK_SLOT_FLOATS | H slots: ranges x SK_SLOT_FLOATS]
 }  // namespace
 
 template <int NWAVES, bool XCD_REMAP>
-__global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kernel(const TdAttnParams p, float* __restrict__ ws_slots,
-                                                                                  unsigned* __restrict__ ws_header, const int n_qblk, const int nt) {
+__global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kernel(const TdAttnParams p, char* __restrict__ ws,
+                                                                                  const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1 | ticket word]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h5 = lane >> 5;
   const int l31 = lane & 31;
+  unsigned* const cnt = (unsigned*)ws + 16;
+  TD_LDS unsigned* const ticket_lds = (TD_LDS unsigned*)(smem + 4 * TILE_BYTES);
 
   // logical range of this workgroup: with XCD_REMAP, workgroups that share an XCD (equal blockIdx % 8 under round-robin
   // placement; speed only) take neighbouring ranges = neighbouring query tiles of the same heads = the same K/V in that L2
@@ -553,55 +562,55 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       }
       if (t < ke) tile(t, std::integral_constant<unsigned, 0>{});
     }
-    // ---- what happens to the state: hand it over, merge a handed-over one, or just finish -------------------------------
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)ws_slots, 0, (unsigned)G * SK_SLOT_FLOATS * 4u, 0x00020000);
-    const unsigned lane_off = ((unsigned)wid * 17u * 64u + (unsigned)lane) * 16u;      // [wave][chunk 0..16][lane] x 16 bytes
-    if (kb > 0) {
-      // TAIL part (always runs to the item's end): publish into slot r.  Write-through stores, drained by every wave.
-      const unsigned base = (unsigned)r * (SK_SLOT_FLOATS * 4u) + lane_off;
+    // ---- what happens to the state: leave it for the other owner, combine with the other owner's, or just finish ----------
+    if (kb > 0 || ke < nt) {
+      const int j = kb > 0 ? r : r + 1;                  // boundary between ranges j-1 (head part) and j (tail part)
+      const bool tail = kb > 0;
+      const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + SK_HEADER_BYTES), 0, (unsigned)(2 * G) * SK_SLOT_FLOATS * 4u, 0x00020000);
+      const unsigned lane_off = ((unsigned)wid * 17u * 64u + (unsigned)lane) * 16u;      // [wave][chunk 0..16][lane] x 16 bytes
+      const unsigned mine = (unsigned)(tail ? j : G + j) * (SK_SLOT_FLOATS * 4u) + lane_off;      // T[j] / H[j]
+      const unsigned theirs = (unsigned)(tail ? G + j : j) * (SK_SLOT_FLOATS * 4u) + lane_off;
+      // one lane asks, everyone hears the answer through LDS (block-uniform control flow below)
+      auto ask = [&](bool draw) -> unsigned {
+        __syncthreads();
+        if (tid == 0)
+          *ticket_lds = draw ? __hip_atomic_fetch_add(cnt + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : __hip_atomic_load(cnt + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        return *ticket_lds;
+      };
+      bool other_ready = !tail && ask(false) == 1u;      // head part: the tail part's owner has normally long been through
+      if (!other_ready) {
+        // leave the state for the other owner: write-through stores, drained by every wave, then the ticket
 #pragma unroll
-      for (int q4 = 0; q4 < 16; ++q4) {
-        const u32x4_t v = {as_u32(o[q4 >> 2][4 * (q4 & 3)]), as_u32(o[q4 >> 2][4 * (q4 & 3) + 1]),
-                           as_u32(o[q4 >> 2][4 * (q4 & 3) + 2]), as_u32(o[q4 >> 2][4 * (q4 & 3) + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsS, base + q4 * 1024u, 0, 16);       // aux 16 = sc1
-      }
-      const u32x4_t ml = {as_u32(m_run), as_u32(l_run), 0u, 0u};
-      __builtin_amdgcn_raw_buffer_store_b128(ml, rsS, base + 16 * 1024u, 0, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(ws_header + 16 + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    if (ke < nt) {
-      // HEAD part: the rest of the item was run by the owner of logical range r + 1, as the first thing it did
-      if (tid == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(ws_header + 16 + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1u << 24)) {                      // seconds: the producer never ran; record it and stop waiting
-            __hip_atomic_store(ws_header, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
+        for (int q4 = 0; q4 < 16; ++q4) {
+          const u32x4_t v = {as_u32(o[q4 >> 2][4 * (q4 & 3)]), as_u32(o[q4 >> 2][4 * (q4 & 3) + 1]),
+                             as_u32(o[q4 >> 2][4 * (q4 & 3) + 2]), as_u32(o[q4 >> 2][4 * (q4 & 3) + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, mine + q4 * 1024u, 0, 16);       // aux 16 = sc1
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const u32x4_t ml = {as_u32(m_run), as_u32(l_run), 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(ml, rsS, mine + 16 * 1024u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        other_ready = ask(true) == 1u;                   // the barrier inside orders every wave's drain before the add
+        if (!other_ready) continue;                      // first to arrive: the other owner finishes the item
       }
+      // second to arrive: the other state is complete and published before the atomic that told us
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const unsigned base = (unsigned)(r + 1) * (SK_SLOT_FLOATS * 4u) + lane_off;
-      const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(rsS, base + 16 * 1024u, 0, 0);
+      const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(rsS, theirs + 16 * 1024u, 0, 0);
       const float m2 = as_f32(ml[0]), l2 = as_f32(ml[1]);
       const float mm = fmaxf(m_run, m2);
       const float a1 = __builtin_amdgcn_exp2f((m_run - mm) * c), a2 = __builtin_amdgcn_exp2f((m2 - mm) * c);
       l_run = l_run * a1 + l2 * a2;
 #pragma unroll
       for (int q4 = 0; q4 < 16; ++q4) {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsS, base + q4 * 1024u, 0, 0);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsS, theirs + q4 * 1024u, 0, 0);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
           o[q4 >> 2][4 * (q4 & 3) + k4] = o[q4 >> 2][4 * (q4 & 3) + k4] * a1 + as_f32(v[k4]) * a2;
       }
-      __syncthreads();          // every wave has its copy: the flag may be cleared for the next launch
-      if (tid == 0) __hip_atomic_store(ws_header + 16 + r + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(cnt + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // both tickets drawn: ready for the next launch
     }
 
     // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] ------------------------------------------
@@ -626,20 +635,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
 
 namespace {
 
-// Per-device stream-K workspace (35 MB of slots + a 4 KB header), created on the first launch that needs it -- call
-// td_attention_bf16 once on a device before capturing it into a hipGraph.
-int sk_workspace(int dev, int ranges, hipStream_t stream, SkWorkspace* out) {
+size_t sk_ws_bytes(int ranges) { return (size_t)SK_HEADER_BYTES + (size_t)2 * ranges * SK_SLOT_FLOATS * sizeof(float); }
+
+// Workspaces for callers that bring none (the plain C entry point): one per (device, stream), created on the first launch
+// that needs it -- call td_attention_bf16 once per stream before capturing it into a hipGraph.  Concurrent launches must
+// not share a workspace, and launches on one stream never overlap.
+int sk_pooled_workspace(int dev, int ranges, hipStream_t stream, char** out) {
+  struct Entry { int dev; hipStream_t stream; int ranges; char* ws; };
   static std::mutex mu;
-  static SkWorkspace ws[64] = {};
+  static std::vector<Entry> pool;
   std::lock_guard<std::mutex> lock(mu);
-  SkWorkspace& w = ws[dev & 63];
-  if (!w.slots || w.ranges < ranges) {
-    if (w.slots) { TD_CHECK_HIP(hipFree(w.slots)); TD_CHECK_HIP(hipFree(w.header)); w = SkWorkspace{}; }
-    TD_CHECK_HIP(hipMalloc((void**)&w.slots, (size_t)ranges * SK_SLOT_FLOATS * sizeof(float)));
-    TD_CHECK_HIP(hipMalloc((void**)&w.header, SK_HEADER_WORDS * sizeof(unsigned)));
-    TD_CHECK_HIP(hipMemset(w.header, 0, SK_HEADER_WORDS * sizeof(unsigned)));
-    w.ranges = ranges;
-  }
+  for (auto& e : pool)
+    if (e.dev == dev && e.stream == stream && e.ranges >= ranges) { *out = e.ws; return 0; }
+  char* w = nullptr;
+  TD_CHECK_HIP(hipMalloc((void**)&w, sk_ws_bytes(ranges)));
+  TD_CHECK_HIP(hipMemset(w, 0, SK_HEADER_BYTES));
+  pool.push_back(Entry{dev, stream, ranges, w});
   *out = w;
   return 0;
 }
@@ -696,17 +707,19 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   // variant 1 = the one-workgroup-per-item kernel for every shape (in-process A/B); variant 2 = stream-K without the XCD remap.
   const int n_items = (int)(grid.x * grid.y * grid.z);
   const int cus = device_cus(dev);
-  if (!p.causal && !p.bias && !p.kv_lens && p.variant != 1 && cus > 0 && n_items > cus && cus + 16 < SK_HEADER_WORDS) {
-    SkWorkspace ws;
-    const int rc = sk_workspace(dev, cus, stream, &ws);
-    if (rc) return rc;
-    const int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
+  const int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
+  if (!p.causal && !p.bias && !p.kv_lens && p.variant != 1 && cus > 0 && n_items > cus && cus < SK_MAX_RANGES && (long long)n_items * nt < (1ll << 31)) {
+    char* ws = (char*)p.sk_ws;
+    if (!ws) {
+      if (int rc = sk_pooled_workspace(dev, cus, stream, &ws)) return rc;
+    }
+    constexpr int lds_sk = lds + 16;        // + the ticket word
     if (p.variant == 2) {
-      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, false>, lds, a4, dev)) return e;
-      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, false>), dim3(cus), dim3(NW * 64), lds, stream, q, ws.slots, ws.header, (int)grid.x, nt);
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, false>, lds_sk, a4, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, false>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
     } else {
-      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true>, lds, a5, dev)) return e;
-      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true>), dim3(cus), dim3(NW * 64), lds, stream, q, ws.slots, ws.header, (int)grid.x, nt);
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true>, lds_sk, a5, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
     }
     TD_CHECK_LAUNCH();
     return 0;
@@ -730,4 +743,13 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   }
   TD_CHECK_LAUNCH();
   return 0;
+}
+
+// bytes of the stream-K hand-off workspace td_attn_launch wants in TdAttnParams::sk_ws on the current device (zero-filled
+// once by the owner; one per concurrently running launch, e.g. one per engine context)
+size_t td_attn_streamk_ws_bytes() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  const int cus = device_cus(dev);
+  return cus > 0 && cus < SK_MAX_RANGES ? sk_ws_bytes(cus) : 0;
 }

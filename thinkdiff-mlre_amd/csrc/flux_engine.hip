@@ -82,6 +82,8 @@ struct td_flux {
   std::vector<DoubleW8> dbl8;
   std::vector<SingleW8> sgl8;
   uint8_t *xq = nullptr, *aq = nullptr;     // per-context, part of the workspace
+  char* attn_ws = nullptr;                  // hand-off workspace of the persistent attention kernel (per context: contexts run concurrently)
+  int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
   float *xs = nullptr, *as_ = nullptr;
   // a forked context (td_flux_fork) shares the parent's weights (bf16 arena, fp8 arena, precision) and owns its
   // workspace, conditioning and schedule: several images in flight on separate streams fill each other's kernel tails
@@ -242,6 +244,7 @@ int alloc_workspace(td_flux* f) {
       {(void**)&f->cosT, S * 128 * 4}, {(void**)&f->sinT, S * 128 * 4}, {(void**)&f->ids, S * 3 * 4},
       {(void**)&f->tvals, (n + 1) * 4},
       {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
+      {(void**)&f->attn_ws, (int64_t)td_attn_streamk_ws_bytes()},
   };
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
@@ -588,7 +591,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   rp.cos = f->cosT; rp.sin = f->sinT; rp.split = T; rp.eps = 1e-6f;
   TdAttnParams ap;
   ap.Q = f->qkv; ap.K = f->qkv + D; ap.V = f->qkv + 2 * D; ap.ldq = ap.ldkv = 3 * D;
-  ap.Sq = ap.Skv = S; ap.Hq = ap.Hkv = H; ap.scale = scale; ap.batch = 1;
+  ap.Sq = ap.Skv = S; ap.Hq = ap.Hkv = H; ap.scale = scale; ap.batch = 1; ap.sk_ws = f->attn_ws; ap.variant = f->attn_variant;
 
   // fp8 mode: the LayerNorm-modulate kernel emits e4m3 rows + per-token scales directly; attention / MLP outputs
   // get a per-token quantisation pass; every block GEMM then runs on the fp8 MFMA path.
@@ -737,13 +740,20 @@ int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, c
   TD_CHECK_ARG(fs && latents && sigmas && streams && count > 0, "td_flux_denoise_multi: null argument");
   for (int k = 0; k < count; ++k)
     TD_CHECK_ARG(fs[k] && latents[k] && n > 0 && n <= fs[k]->n_steps, "td_flux_denoise_multi: context %d is not prepared for %d steps", k, n);
-  for (int i = 0; i < n; ++i)
-    for (int k = 0; k < count; ++k) {
+  // With several images in flight the attention of each runs as a plain grid (one workgroup per item): its second, 59 %-empty
+  // round is exactly what the other images' kernels fill, while the persistent form holds every CU for its whole duration
+  // and shuts them out (measured, 3 in flight: 0.698 images/s persistent vs 0.71 plain; one image alone: 0.678 vs 0.655).
+  for (int k = 0; k < count; ++k) fs[k]->attn_variant = count > 1 ? 1 : 0;
+  int rc = TD_OK;
+  for (int i = 0; i < n && rc == TD_OK; ++i)
+    for (int k = 0; k < count && rc == TD_OK; ++k) {
       td_flux* f = fs[k];
-      TD_TRY(td_flux_forward(f, latents[k], i, f->vout, streams[k]));
-      TD_TRY(td_euler_step_launch((bf16_t*)latents[k], f->vout, sigmas[i + 1] - sigmas[i], (long long)f->S_img * f->cfg.in_channels, (hipStream_t)streams[k]));
+      rc = td_flux_forward(f, latents[k], i, f->vout, streams[k]);
+      if (rc == TD_OK)
+        rc = td_euler_step_launch((bf16_t*)latents[k], f->vout, sigmas[i + 1] - sigmas[i], (long long)f->S_img * f->cfg.in_channels, (hipStream_t)streams[k]);
     }
-  return TD_OK;
+  for (int k = 0; k < count; ++k) fs[k]->attn_variant = 0;
+  return rc;
 }
 
 }  // extern "C"

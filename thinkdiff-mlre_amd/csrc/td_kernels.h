@@ -62,7 +62,11 @@ struct TdAttnParams {
   const float* bias = nullptr;
   // optional per-batch cache length (device int[batch], causal kernel): sequence b attends keys [0, kv_lens[b]); Skv = the largest
   const int* kv_lens = nullptr;
+  // optional hand-off workspace of the persistent (stream-K) joint-attention kernel: td_attn_streamk_ws_bytes() bytes, zeroed
+  // once by its owner, not shared by launches that may run concurrently (null: a per-(device, stream) one is created inside)
+  void* sk_ws = nullptr;
 };
+size_t td_attn_streamk_ws_bytes();
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);
 // Sq = 1 (KV-cached decode) form, csrc/attention_decode.hip; td_attn_launch routes to it
