@@ -143,7 +143,7 @@ def _pmc_traffic(kernel):
         with open(fn) as fh:
             prof = json.load(fh)
         for name, v in prof["kernels"].items():
-            if want in name.replace(" ", "") and ",false>" in name.replace(" ", ""):
+            if want in name.replace(" ", "") and "false,false>" in name.replace(" ", ""):       # not the conv / fp8 instantiations
                 return {"traffic": v["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
                         "traffic_source": f"{os.path.basename(fn)}: {prof['source']}; {prof['correction']}"}
     return {"traffic": None}

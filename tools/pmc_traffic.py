@@ -39,7 +39,7 @@ def main():
         out[k] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                   "raw_FETCH_SIZE_KiB_per_launch": f / max(n, 1), "raw_WRITE_SIZE_KiB_per_launch": w / max(nw, 1)}
     with open(sys.argv[3], "w") as fh:
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-trace --no-fp8-leg",
                    "correction": "read = 2 x FETCH_SIZE x 1024 B (gfx950 128-B requests tallied at 64 B), write = WRITE_SIZE x 1024 B",
                    "kernels": out}, fh, indent=1)
     for k, v in list(out.items())[:8]:
