@@ -8,7 +8,8 @@
  * Conventions
  *  - every `const void*` / `void*` tensor argument is a DEVICE pointer (HBM), 16-byte aligned,
  *    borrowed for the duration of the call; bf16 tensors are raw uint16 bit patterns, row-major;
- *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work, never synchronise;
+ *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work and never synchronise (exceptions, by
+ *    purpose: td_*_create / td_flux_set_precision allocate, td_flux_trace_end reads its events back);
  *  - return value: TD_OK or an error code; td_last_error() returns a thread-local message;
  *  - no entry point allocates device memory except td_flux_create / td_*_create (workspaces are
  *    sized once at creation), so every call is hipGraph-capturable.
@@ -40,7 +41,8 @@ int td_linear_bf16(const void* x, int64_t ldx, const void* w, const void* bias, 
 
 /* Same contraction with two outputs: columns [0,n_split) -> y0 (act0), columns [n_split,N) -> y1
  * (act1).  This is FluxSingleTransformerBlock's fused [to_q|to_k|to_v|proj_mlp] projection
- * ([ext] transformer_flux.py FluxSingleTransformerBlock.forward). n_split % 256 == 0. */
+ * ([ext] transformer_flux.py FluxSingleTransformerBlock.forward).  n_split must be a multiple of the N tile the launcher
+ * picks for the shape (64, 192 or 256 columns; 256 always qualifies -- TD_ERR_INVALID otherwise). */
 int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* bias,
                          void* y0, int64_t ldy0, int act0, void* y1, int64_t ldy1, int act1,
                          int M, int N, int K, int n_split, void* stream);

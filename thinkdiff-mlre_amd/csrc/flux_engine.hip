@@ -84,6 +84,7 @@ struct td_flux {
   uint8_t *xq = nullptr, *aq = nullptr;     // per-context, part of the workspace
   char* attn_ws = nullptr;                  // hand-off workspace of the persistent attention kernel (per context: contexts run concurrently)
   int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
+  std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
   // a forked context (td_flux_fork) shares the parent's weights (bf16 arena, fp8 arena, precision) and owns its
   // workspace, conditioning and schedule: several images in flight on separate streams fill each other's kernel tails
@@ -549,11 +550,11 @@ int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, vo
   TD_CHECK_ARG(f->cond_set, "td_flux_set_timesteps: call td_flux_set_condition first (temb includes the pooled text embedding)");
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D;
-  std::vector<float> tv(t_eff, t_eff + n);
-  tv.push_back(g_eff);
-  // pageable H2D copy of <= 260 bytes: synchronous w.r.t. the host buffer, ordered on the stream
-  TD_CHECK_HIP(hipMemcpyAsync(f->tvals, tv.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
-  TD_CHECK_HIP(hipStreamSynchronize(s));
+  // the scalars travel as a <= 260-byte pageable H2D copy ordered on the stream; the staging vector belongs to the context and
+  // outlives the copy, so nothing here waits for the stream
+  f->tv_host.assign(t_eff, t_eff + n);
+  f->tv_host.push_back(g_eff);
+  TD_CHECK_HIP(hipMemcpyAsync(f->tvals, f->tv_host.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
   TD_TRY(td_timestep_sincos_launch(f->tvals, n, f->tproj, s));
   TD_TRY(gemm(f, s, f->tproj, 256, f->t1_w, f->t1_b, f->tmid, D, n, D, 256, TD_ACT_SILU));
   TD_TRY(gemm(f, s, f->tmid, D, f->t2_w, f->t2_b, f->te, D, n, D, D));
