@@ -76,6 +76,38 @@ def test_joint_attention_more_items_than_cus(hip, B, S, H):
     _check(outs[0], ref)
 
 
+def test_persistent_attention_concurrent_streams(hip):
+    """Three persistent (stream-K) attention launches share the chip on three streams, many times over, beside an unrelated
+    memory-bound kernel on a fourth: every result must equal the same launch run alone.  The split items' two owners never
+    wait for each other (second arriver merges), so no residency or dispatch-order assumption is involved; each stream has its
+    own hand-off workspace."""
+    S, H, reps = 4289, 24, 12
+    W = H * 128
+    g = torch.Generator().manual_seed(77)
+    ins = [torch.randn(1, S, 3 * W, generator=g).bfloat16().cuda() for _ in range(3)]
+    alone = []
+    for x in ins:
+        o = torch.zeros(1, S, W, dtype=torch.bfloat16, device="cuda")
+        hip.attention(x[:, :, :W], x[:, :, W:2 * W], x[:, :, 2 * W:], o, H, H)
+        torch.cuda.synchronize()
+        alone.append(o)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    noise = torch.empty(64 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
+    outs = [[torch.zeros(1, S, W, dtype=torch.bfloat16, device="cuda") for _ in range(reps)] for _ in range(3)]
+    torch.cuda.synchronize()
+    for r in range(reps):
+        for k in range(3):
+            with torch.cuda.stream(streams[k]):
+                x = ins[k]
+                hip.attention(x[:, :, :W], x[:, :, W:2 * W], x[:, :, 2 * W:], outs[k][r], H, H)
+        with torch.cuda.stream(streams[3]):
+            noise.add_(1.0)                       # uneven load on the memory system while the hand-offs happen
+    torch.cuda.synchronize()
+    for k in range(3):
+        for r in range(reps):
+            assert torch.equal(outs[k][r], alone[k]), f"stream {k} repetition {r} differs from the launch run alone"
+
+
 def test_attention_peaked_rows(hip):
     """Forces the online-softmax rescale: one key per row dominates late in the sequence."""
     g = torch.Generator().manual_seed(3)

@@ -602,13 +602,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       const float m2 = as_f32(ml[0]), l2 = as_f32(ml[1]);
       const float mm = fmaxf(m_run, m2);
       const float a1 = __builtin_amdgcn_exp2f((m_run - mm) * c), a2 = __builtin_amdgcn_exp2f((m2 - mm) * c);
-      l_run = l_run * a1 + l2 * a2;
+      // One operation order whoever merges -- fma(head, a_head, tail * a_tail) -- so the result does not depend on which owner
+      // arrived second (it does under load; the sum is otherwise the same to one fp32 rounding).
+      auto comb = [&](float own, float other) {
+        return tail ? __builtin_fmaf(other, a2, own * a1) : __builtin_fmaf(own, a1, other * a2);
+      };
+      l_run = comb(l_run, l2);
 #pragma unroll
       for (int q4 = 0; q4 < 16; ++q4) {
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsS, theirs + q4 * 1024u, 0, 0);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
-          o[q4 >> 2][4 * (q4 & 3) + k4] = o[q4 >> 2][4 * (q4 & 3) + k4] * a1 + as_f32(v[k4]) * a2;
+          o[q4 >> 2][4 * (q4 & 3) + k4] = comb(o[q4 >> 2][4 * (q4 & 3) + k4], as_f32(v[k4]));
       }
       if (tid == 0) __hip_atomic_store(cnt + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // both tickets drawn: ready for the next launch
     }
