@@ -1,0 +1,161 @@
+// torch.ops.thinkdiff_hip.* -- the custom-op layer of the MI355X hot path (last row), registered from a
+// shared library (lib/libthinkdiff_torch_ops.so, loaded by thinkdiff/ops.py with torch.ops.load_library).
+//
+// Each op is a schema plus ONE kernel, registered for the "CUDA" (= HIP on ROCm) dispatch key, that hands raw device pointers
+// and sizes to the C ABI of libthinkdiff_hip.so (include/thinkdiff_hip.h).  Conventions: tensors are borrowed (caller owns,
+// device-resident, innermost stride 1), outputs come from the PyTorch caching allocator on the current HIP stream, nothing
+// synchronises, a rejected argument is a TORCH_CHECK failure (Python RuntimeError) carrying td_last_error().  There is no CPU,
+// Meta or composite kernel: host tensors fail in the dispatcher instead of computing somewhere else.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "../../include/thinkdiff_hip.h"
+
+namespace {
+
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+const void* P(const c10::optional<at::Tensor>& t) { return t.has_value() && t->defined() ? t->data_ptr() : nullptr; }
+
+void check_rows(const at::Tensor& t, const char* name, at::ScalarType ty = at::kBFloat16) {
+  TORCH_CHECK(t.is_cuda(), "thinkdiff_hip: ", name, " must live on the GPU");
+  TORCH_CHECK(t.scalar_type() == ty, "thinkdiff_hip: ", name, " has dtype ", t.scalar_type(), ", expected ", ty);
+  TORCH_CHECK(t.dim() >= 1 && t.stride(-1) == 1, "thinkdiff_hip: ", name, " needs innermost stride 1");
+}
+void ok(int rc) { TORCH_CHECK(rc == TD_OK, "libthinkdiff_hip error ", rc, ": ", td_last_error()); }
+
+// y = act(x . w^T + bias) * gate + res      (nn.Linear and its fused neighbours)
+at::Tensor linear(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t act,
+                  const c10::optional<at::Tensor>& gate, const c10::optional<at::Tensor>& res) {
+  check_rows(x, "x"); check_rows(w, "w");
+  TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.is_contiguous() && w.size(1) == x.size(1), "thinkdiff_hip::linear: x [M,K], w [N,K] contiguous");
+  at::Tensor y = at::empty({x.size(0), w.size(0)}, x.options());
+  const int64_t ldr = res.has_value() && res->defined() ? res->stride(0) : 0;
+  ok(td_linear_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), P(bias), y.data_ptr(), y.stride(0), (int)x.size(0), (int)w.size(0),
+                    (int)x.size(1), (int)act, P(gate), P(res), ldr, stream_of(x)));
+  return y;
+}
+
+// ThinkDiff aligner mm_projector "mlp2x_gelu_t5_norm": T5LayerNorm(Linear2(GELU_erf(Linear0(x))))
+at::Tensor aligner_mlp2x(const at::Tensor& x, const at::Tensor& w0, const at::Tensor& b0, const at::Tensor& w2, const at::Tensor& b2,
+                         const at::Tensor& norm_w, double eps, bool fp32_norm) {
+  check_rows(x, "x"); check_rows(w0, "w0"); check_rows(w2, "w2");
+  TORCH_CHECK(x.dim() == 2, "thinkdiff_hip::aligner_mlp2x: x [M,K]");
+  const int64_t M = x.size(0), K = x.size(1), H = w0.size(0);
+  at::Tensor ws = at::empty({2 * M * H}, x.options());
+  at::Tensor y = at::empty({M, H}, x.options());
+  ok(td_aligner_mlp2x_bf16(x.data_ptr(), x.stride(0), (int)M, (int)K, (int)H, w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                           norm_w.data_ptr(), (float)eps, fp32_norm ? 1 : 0, ws.data_ptr(), y.data_ptr(), H, stream_of(x)));
+  return y;
+}
+
+// softmax(q.k^T * scale [+ causal mask]) . v on token-major fused projections: q [B,Sq,>=Hq*128], k/v [B,Skv,>=Hkv*128]
+at::Tensor attention(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, int64_t Hq, int64_t Hkv, double scale, bool causal) {
+  check_rows(q, "q"); check_rows(k, "k"); check_rows(v, "v");
+  TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3 && k.strides() == v.strides(), "thinkdiff_hip::attention: q/k/v [B,S,cols], k and v with equal strides");
+  at::Tensor o = at::empty({q.size(0), q.size(1), Hq * 128}, q.options());
+  ok(td_attention_bf16(q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(1), k.stride(0), o.data_ptr(),
+                       o.stride(1), o.stride(0), (int)q.size(0), (int)q.size(1), (int)k.size(1), (int)Hq, (int)Hkv, 128, (float)scale,
+                       causal ? 1 : 0, stream_of(q)));
+  return o;
+}
+
+// LayerNorm (no affine) / RMSNorm rows with optional adaLN modulation y*(1+scale)+shift (set A for rows < split, set B after)
+at::Tensor norm_rows(const at::Tensor& x, bool rms, double eps, const c10::optional<at::Tensor>& w, int64_t split,
+                     const c10::optional<at::Tensor>& shiftA, const c10::optional<at::Tensor>& scaleA,
+                     const c10::optional<at::Tensor>& shiftB, const c10::optional<at::Tensor>& scaleB) {
+  check_rows(x, "x");
+  TORCH_CHECK(x.dim() == 2, "thinkdiff_hip::norm_rows: x [rows,D]");
+  at::Tensor y = at::empty_like(x);
+  ok(td_norm_rows_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), (int)x.size(0), (int)x.size(1), rms ? 1 : 0, (float)eps, P(w),
+                       (int)split, P(shiftA), P(scaleA), P(shiftB), P(scaleB), stream_of(x)));
+  return y;
+}
+
+// in-place per-head RMSNorm(q), RMSNorm(k) + rotary embedding on a fused projection buffer
+at::Tensor& qk_norm_rope_(at::Tensor& qkv, int64_t Hq, int64_t Hk, int64_t q_col, int64_t k_col, const at::Tensor& cos, const at::Tensor& sin,
+                          int64_t split, const c10::optional<at::Tensor>& wqA, const c10::optional<at::Tensor>& wkA,
+                          const c10::optional<at::Tensor>& wqB, const c10::optional<at::Tensor>& wkB, double eps, bool rotate_half) {
+  check_rows(qkv, "qkv"); check_rows(cos, "cos", at::kFloat); check_rows(sin, "sin", at::kFloat);
+  TORCH_CHECK(qkv.dim() == 2 && cos.is_contiguous() && sin.is_contiguous() && cos.size(0) == qkv.size(0) && cos.size(1) == 128,
+              "thinkdiff_hip::qk_norm_rope_: qkv [rows,cols], cos/sin fp32 [rows,128]");
+  ok(td_qk_norm_rope_bf16(qkv.data_ptr(), qkv.stride(0), (int)qkv.size(0), (int)Hq, (int)Hk, (int)q_col, (int)k_col, (const float*)cos.data_ptr(),
+                          (const float*)sin.data_ptr(), (int)split, P(wqA), P(wkA), wqB.has_value() && wqB->defined() ? P(wqB) : P(wqA),
+                          wkB.has_value() && wkB->defined() ? P(wkB) : P(wkA), (float)eps, rotate_half ? 1 : 0, stream_of(qkv)));
+  return qkv;
+}
+
+// FlowMatchEulerDiscreteScheduler.step in place: x = bf16(float(x) + dt * float(v))
+at::Tensor& euler_step_(at::Tensor& x, const at::Tensor& v, double dt) {
+  check_rows(x, "x"); check_rows(v, "v");
+  TORCH_CHECK(x.is_contiguous() && v.is_contiguous() && x.numel() == v.numel(), "thinkdiff_hip::euler_step_: contiguous x, v of equal size");
+  ok(td_euler_step_bf16(x.data_ptr(), v.data_ptr(), (float)dt, x.numel(), stream_of(x)));
+  return x;
+}
+
+at::Tensor flux_pack_latents(const at::Tensor& latents) {            // [C,H,W] -> [(H/2)(W/2), 4C]
+  check_rows(latents, "latents");
+  TORCH_CHECK(latents.dim() == 3 && latents.is_contiguous(), "thinkdiff_hip::flux_pack_latents: contiguous [C,H,W]");
+  const int64_t C = latents.size(0), H = latents.size(1), W = latents.size(2);
+  at::Tensor out = at::empty({(H / 2) * (W / 2), C * 4}, latents.options());
+  ok(td_flux_pack_latents(latents.data_ptr(), out.data_ptr(), (int)C, (int)H, (int)W, 0, 1.0f, 0.0f, stream_of(latents)));
+  return out;
+}
+
+at::Tensor flux_unpack_latents(const at::Tensor& packed, int64_t C, int64_t H, int64_t W, double div, double add) {   // bf16(bf16(x / div) + add)
+  check_rows(packed, "packed");
+  TORCH_CHECK(packed.is_contiguous() && packed.numel() == C * H * W, "thinkdiff_hip::flux_unpack_latents: contiguous [(H/2)(W/2), 4C]");
+  at::Tensor out = at::empty({C, H, W}, packed.options());
+  ok(td_flux_pack_latents(packed.data_ptr(), out.data_ptr(), (int)C, (int)H, (int)W, 1, (float)div, (float)add, stream_of(packed)));
+  return out;
+}
+
+at::Tensor cls_avgpool2(const at::Tensor& tokens) {                  // [1+G*G, C] -> [1+(G/2)^2, C]
+  check_rows(tokens, "tokens");
+  TORCH_CHECK(tokens.dim() == 2 && tokens.is_contiguous(), "thinkdiff_hip::cls_avgpool2: contiguous [1+G*G, C]");
+  int64_t G = 0;
+  while ((G + 1) * (G + 1) <= tokens.size(0) - 1) ++G;
+  TORCH_CHECK(G * G == tokens.size(0) - 1, "thinkdiff_hip::cls_avgpool2: token count must be 1 + G*G");
+  at::Tensor out = at::empty({1 + (G / 2) * (G / 2), tokens.size(1)}, tokens.options());
+  ok(td_cls_avgpool2_bf16(tokens.data_ptr(), out.data_ptr(), (int)G, (int)tokens.size(1), stream_of(tokens)));
+  return out;
+}
+
+// one token per row of bf16 logits: temperature / top-p, drawn from (seed, offset, row); temperature <= 0: greedy
+at::Tensor sample_top_p(const at::Tensor& logits, double temperature, double top_p, int64_t seed, int64_t offset) {
+  check_rows(logits, "logits");
+  at::Tensor x = logits.dim() == 1 ? logits.unsqueeze(0) : logits;
+  TORCH_CHECK(x.dim() == 2, "thinkdiff_hip::sample_top_p: logits [rows, vocab]");
+  at::Tensor out = at::empty({x.size(0)}, x.options().dtype(at::kInt));
+  ok(td_sample_top_p_bf16(x.data_ptr(), x.stride(0), (int)x.size(0), (int)x.size(1), (float)temperature, (float)top_p, (uint64_t)seed,
+                          (uint64_t)offset, (int32_t*)out.data_ptr(), stream_of(x)));
+  return out;
+}
+
+}  // namespace
+
+TORCH_LIBRARY(thinkdiff_hip, m) {
+  m.def("linear(Tensor x, Tensor w, Tensor? bias, int act, Tensor? gate, Tensor? res) -> Tensor");
+  m.def("aligner_mlp2x(Tensor x, Tensor w0, Tensor b0, Tensor w2, Tensor b2, Tensor norm_w, float eps, bool fp32_norm) -> Tensor");
+  m.def("attention(Tensor q, Tensor k, Tensor v, int Hq, int Hkv, float scale, bool causal) -> Tensor");
+  m.def("norm_rows(Tensor x, bool rms, float eps, Tensor? w, int split, Tensor? shiftA, Tensor? scaleA, Tensor? shiftB, Tensor? scaleB) -> Tensor");
+  m.def("qk_norm_rope_(Tensor(a!) qkv, int Hq, int Hk, int q_col, int k_col, Tensor cos, Tensor sin, int split, Tensor? wqA, Tensor? wkA, Tensor? wqB, Tensor? wkB, float eps, bool rotate_half) -> Tensor(a!)");
+  m.def("euler_step_(Tensor(a!) x, Tensor v, float dt) -> Tensor(a!)");
+  m.def("flux_pack_latents(Tensor latents) -> Tensor");
+  m.def("flux_unpack_latents(Tensor packed, int C, int H, int W, float div, float add) -> Tensor");
+  m.def("cls_avgpool2(Tensor tokens) -> Tensor");
+  m.def("sample_top_p(Tensor logits, float temperature, float top_p, int seed, int offset) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(thinkdiff_hip, CUDA, m) {
+  m.impl("linear", &linear);
+  m.impl("aligner_mlp2x", &aligner_mlp2x);
+  m.impl("attention", &attention);
+  m.impl("norm_rows", &norm_rows);
+  m.impl("qk_norm_rope_", &qk_norm_rope_);
+  m.impl("euler_step_", &euler_step_);
+  m.impl("flux_pack_latents", &flux_pack_latents);
+  m.impl("flux_unpack_latents", &flux_unpack_latents);
+  m.impl("cls_avgpool2", &cls_avgpool2);
+  m.impl("sample_top_p", &sample_top_p);
+}

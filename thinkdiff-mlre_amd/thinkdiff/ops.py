@@ -1,13 +1,14 @@
 """`torch.ops.thinkdiff_hip.*`: the custom-op layer of the MI355X hot path (last row).
 
-Each op is a schema registered with `torch.library` whose only kernel is the "CUDA" (= HIP on ROCm) dispatch entry that hands
-raw device pointers to the C ABI of libthinkdiff_hip.so (include/thinkdiff_hip.h) through `thinkdiff._hip`.  Conventions:
-tensors are borrowed (caller owns, device-resident, innermost stride 1), outputs are allocated by the PyTorch caching
-allocator on the current HIP stream, nothing synchronises, errors surface as `RuntimeError` (ThinkDiffHipError), one process
-per GPU.  There is NO CPU / Meta / composite kernel: calling an op with host tensors fails in the dispatcher
-("could not run ... with arguments from the 'CPU' backend") instead of quietly computing somewhere else.
+The ops are registered by a shared library -- `lib/libthinkdiff_torch_ops.so`, built by `make` from `csrc_torch/torch_ops.cpp`
+(TORCH_LIBRARY + TORCH_LIBRARY_IMPL for the "CUDA" = HIP dispatch key) -- whose kernels hand raw device pointers to the C ABI of
+`libthinkdiff_hip.so` (include/thinkdiff_hip.h).  Conventions: tensors are borrowed (caller owns, device-resident, innermost
+stride 1), outputs are allocated by the PyTorch caching allocator on the current HIP stream, nothing synchronises, a rejected
+argument is a `RuntimeError` carrying `td_last_error()`, one process per GPU.  There is NO CPU / Meta / composite kernel: calling
+an op with host tensors fails in the dispatcher instead of quietly computing somewhere else, and importing this module without the
+library raises.
 
-    import thinkdiff.ops                      # registers the namespace (idempotent)
+    import thinkdiff.ops                      # loads the library (idempotent)
     y = torch.ops.thinkdiff_hip.linear(x, w, b, 0, None, None)
 
 Op                         replaces in the reference's stack (details: include/thinkdiff_hip.h)
@@ -18,13 +19,15 @@ qk_norm_rope_              per-head QK-RMSNorm + rotary embedding, in place
 euler_step_                FlowMatchEulerDiscreteScheduler.step, in place
 flux_pack_latents / flux_unpack_latents, cls_avgpool2, sample_top_p
 """
-from typing import Optional
+import os
 
 import torch
 
 from . import _hip
 
-_LIB = None
+OPS_LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libthinkdiff_torch_ops.so")
+
+# the schemas csrc_torch/torch_ops.cpp defines (tests compare them with what the dispatcher reports)
 SCHEMAS = {
     "linear": "(Tensor x, Tensor w, Tensor? bias, int act, Tensor? gate, Tensor? res) -> Tensor",
     "aligner_mlp2x": "(Tensor x, Tensor w0, Tensor b0, Tensor w2, Tensor b2, Tensor norm_w, float eps, bool fp32_norm) -> Tensor",
@@ -38,44 +41,19 @@ SCHEMAS = {
     "sample_top_p": "(Tensor logits, float temperature, float top_p, int seed, int offset) -> Tensor",
 }
 
-
-def _attention(q, k, v, Hq: int, Hkv: int, scale: float, causal: bool):
-    out = torch.empty(q.shape[0], q.shape[1], Hq * 128, dtype=torch.bfloat16, device=q.device)
-    return _hip.attention(q, k, v, out, Hq, Hkv, scale, causal)
-
-
-def _norm_rows(x, rms: bool, eps: float, w: Optional[torch.Tensor], split: int, shiftA, scaleA, shiftB, scaleB):
-    return _hip.norm_rows(x, None, rms, eps, w, split, shiftA, scaleA, shiftB, scaleB)
-
-
-def _qk_norm_rope_(qkv, Hq: int, Hk: int, q_col: int, k_col: int, cos, sin, split: int, wqA, wkA, wqB, wkB, eps: float, rotate_half: bool):
-    return _hip.qk_norm_rope(qkv, Hq, Hk, q_col, k_col, cos, sin, split, wqA, wkA, wqB, wkB, eps, rotate_half)
-
-
-_IMPLS = {
-    "linear": lambda x, w, bias, act, gate, res: _hip.linear(x, w, bias, act, gate, res),
-    "aligner_mlp2x": lambda x, w0, b0, w2, b2, nw, eps, f32: _hip.aligner_mlp2x(x, w0, b0, w2, b2, nw, eps, f32),
-    "attention": _attention,
-    "norm_rows": _norm_rows,
-    "qk_norm_rope_": _qk_norm_rope_,
-    "euler_step_": lambda x, v, dt: _hip.euler_step(x, v, dt),
-    "flux_pack_latents": lambda lat: _hip.flux_pack_latents(lat),
-    "flux_unpack_latents": lambda p, C, H, W, div, add: _hip.flux_unpack_latents(p, C, H, W, div, add),
-    "cls_avgpool2": lambda t: _hip.cls_avgpool2(t),
-    "sample_top_p": lambda lg, T, p, seed, off: _hip.sample_top_p(lg, T, p, seed, off),
-}
+_loaded = False
 
 
 def register():
-    """Define the `thinkdiff_hip` namespace once per process; returns the torch.library.Library handle."""
-    global _LIB
-    if _LIB is None:
-        lib = torch.library.Library("thinkdiff_hip", "DEF")
-        for name, schema in SCHEMAS.items():
-            lib.define(name + schema)
-            lib.impl(name, _IMPLS[name], "CUDA")
-        _LIB = lib
-    return _LIB
+    """Load libthinkdiff_torch_ops.so once per process (its static initialisers define the `thinkdiff_hip` namespace)."""
+    global _loaded
+    if not _loaded:
+        if not os.path.exists(OPS_LIB_PATH):
+            raise _hip.ThinkDiffHipError(f"{OPS_LIB_PATH} not found: build it with `make -C thinkdiff-mlre_amd` "
+                                         "(or __graft_entry__.build()); there is no Python-side stand-in for the op layer")
+        torch.ops.load_library(OPS_LIB_PATH)
+        _loaded = True
+    return torch.ops.thinkdiff_hip
 
 
 register()
