@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip the per-launch HIP-event trace (roofline leg)")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=2,
                     help="independent images advanced concurrently per rank (engine contexts on separate streams); a step = this many images")
     ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
                     help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path")

@@ -202,7 +202,7 @@ class ClipFluxDriver:
             jobs = dp.shard(dp.broadcast_work_list(jobs))
         else:
             jobs = plan_jobs(run, self.seed, self.TWO_IMAGE_DRIVER)
-        G = max(1, int(run.get("images_in_flight", 3)))      # images rendered per pipeline call (MI355X: fills kernel tails)
+        G = max(1, int(run.get("images_in_flight", 2)))      # images rendered per pipeline call (MI355X: fills kernel tails)
         if hasattr(self, "pipe"):
             self.pipe.images_in_flight = G
         written, pending = [], []

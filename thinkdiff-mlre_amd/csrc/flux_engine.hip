@@ -744,7 +744,9 @@ int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, c
   // With several images in flight the attention of each runs as a plain grid (one workgroup per item): its second, 59 %-empty
   // round is exactly what the other images' kernels fill, while the persistent form holds every CU for its whole duration
   // and shuts them out (measured, 3 in flight: 0.698 images/s persistent vs 0.71 plain; one image alone: 0.678 vs 0.655).
-  for (int k = 0; k < count; ++k) fs[k]->attn_variant = count > 1 ? 1 : 0;
+  static const char* force = getenv("TD_FLUX_INFLIGHT_ATTN");      // experiments only: 0 / 1 forces the attention form used with images in flight
+  const int multi_variant = force ? atoi(force) : 1;
+  for (int k = 0; k < count; ++k) fs[k]->attn_variant = count > 1 ? multi_variant : 0;
   int rc = TD_OK;
   for (int i = 0; i < n && rc == TD_OK; ++i)
     for (int k = 0; k < count && rc == TD_OK; ++k) {

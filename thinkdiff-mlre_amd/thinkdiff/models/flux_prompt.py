@@ -53,7 +53,7 @@ class FluxPipelineRewritePrompt:
         self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
         self.transformer = transformer
         self._progress = {}
-        self.images_in_flight = 3          # images of one call advanced concurrently (engine contexts on separate streams)
+        self.images_in_flight = 2          # images of one call advanced concurrently (engine contexts on separate streams; 2 beats 3 and 4 on MI355X)
         self._ctx_pool, self._streams = [], []
 
     def _contexts(self, n: int):
