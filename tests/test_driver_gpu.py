@@ -165,3 +165,64 @@ def test_lvlm_multi_image_drivers(hip, tmp_path):
     assert torch.equal(pooled, d.text.clip_pooled(d.QUESTION, d.device).to(torch.bfloat16))                                     # CLIP(question)
     written = d.run()
     assert [os.path.basename(w) for w in written] == ["LAIONEval4000_0_output_embed_edit_4_flux_0_thinkdiff_lvlm.pth_seed_42.png"]   # reference :337
+
+
+def test_lvlm_embed_export_drivers(hip, tmp_path):
+    """Reference scripts/test/test_mllama_t5_decoder_flux_embed.py, ..._embed_multi_image.py, ..._embed_multi_image_batch.py
+    and ..._multi_image_input_embed.py in miniature: the aligner output lands on disk as {name}.pth + {name}.json (or, for the
+    text-only driver, conditions FLUX); the batched export writes the same tensors as the one-at-a-time export."""
+    import io
+    import json
+
+    import torch
+    from scripts.test import test_mllama_t5_decoder_flux_embed as emb
+    from scripts.test import test_mllama_t5_decoder_flux_embed_multi_image as mi
+    from scripts.test import test_mllama_t5_decoder_flux_embed_multi_image_batch as mib
+    from scripts.test import test_mllama_t5_decoder_flux_multi_image_input_embed as txt
+    common = ["--cfg-path", os.path.join(HERE, "golden", "thinkdiff_lvlm_driver_keys.yaml"), "--options",
+              "run.synthetic=true", "run.synthetic_tiny=true", "run.distributed=false", "model.ckpt=/ckpts/thinkdiff_lvlm.pth",
+              "model.vllm_config.max_model_len=1024", "model.vllm_config.max_tokens=16", "model.vllm_config.min_tokens=16",
+              "model.text_config={hidden_size: 512, num_hidden_layers: 2, num_attention_heads: 4, num_key_value_heads: 2, intermediate_size: 1024, vocab_size: 152064}"]
+    src = tmp_path / "in"
+    src.mkdir()
+    imgs = []
+    for k, col in enumerate([(250, 250, 250), (20, 30, 220), (200, 30, 20)]):
+        p = src / f"car{k}.jpg"
+        Image.new("RGB", (140, 112), col).save(p)
+        (src / f"car{k}.json").write_text(json.dumps({"caption": f"car {k}"}))
+        imgs.append(str(p))
+
+    # one image + run.prompt -> car{k}.pth / car{k}.json; a rendered car1.png in the output directory masks car1 (:146-150)
+    out = tmp_path / "emb"
+    out.mkdir()
+    Image.new("RGB", (8, 8)).save(out / "car1.png")
+    written = emb.main(common + [f"run.output_dir={out}", f"run.image_folder={src}", "run.prompt=Describe the car."])
+    assert sorted(os.path.basename(w) for w in written) == ["car0.json", "car0.pth", "car2.json", "car2.pth"]
+    e0 = torch.load(io.BytesIO(open(out / "car0.pth", "rb").read()))
+    assert e0.device.type == "cpu" and e0.shape == (16, 4096) and torch.isfinite(e0.float()).all()
+    j0 = json.load(open(out / "car0.json"))
+    assert list(j0) == ["caption", "generated_text", "prompt"] and j0["prompt"] == "Describe the car." and j0["caption"] == "car 0"
+
+    # interleaved word / picture tasks, one at a time and in batches of 2
+    tasks_dir = tmp_path / "tasks"
+    tasks_dir.mkdir()
+    for k in range(3):
+        (tasks_dir / f"task{k}.json").write_text(json.dumps({"text_inputs": ["white: ", "blue: ", "red: "][k:] + ["green: "], "image_inputs": imgs[k:][:2]}))
+    one, many = tmp_path / "one", tmp_path / "many"
+    opts = [f"run.image_folder={tasks_dir}", "run.prompt=What is the next picture?", "run.max_pixels=65536"]
+    w1 = mi.main(common + [f"run.output_dir={one}"] + opts)
+    assert sorted(os.path.basename(w) for w in w1) == sorted(f"task{k}.{x}" for k in range(3) for x in ("pth", "json"))
+    assert mi.main(common + [f"run.output_dir={one}"] + opts) == []                       # every .pth exists -> nothing to do
+    wb = mib.main(common + [f"run.output_dir={many}", "run.batch_size=2"] + opts)
+    assert sorted(os.path.basename(w) for w in wb) == sorted(os.path.basename(w) for w in w1)
+    for k in range(3):
+        a, b = torch.load(one / f"task{k}.pth"), torch.load(many / f"task{k}.pth")
+        assert a.shape == b.shape == (16, 4096)
+        ja, jb = json.load(open(one / f"task{k}.json")), json.load(open(many / f"task{k}.json"))
+        assert ja["prompt"] == jb["prompt"] == "What is the next picture?" and ja["text_inputs"] == jb["text_inputs"]
+
+    # text-only prompt -> aligner tokens padded to run.max_tokens -> FLUX 512^2
+    out = tmp_path / "txt"
+    written = txt.main(common + [f"run.output_dir={out}", "run.max_tokens=24"])
+    assert [os.path.basename(w) for w in written] == ["skateboard_edit_4_flux_output_embed_0_thinkdiff_lvlm.pth.png"]   # reference :289
+    assert Image.open(written[0]).size == (512, 512)

@@ -224,3 +224,55 @@ def test_sharded_driver_job_list_two_ranks(tmp_path):
     assert len(files1) == 10 and files1 == files2
     assert [os.path.basename(p) for p in res1] == [os.path.basename(p) for p in res2]
     assert os.path.basename(res2[3]) == "x1_y1_clip_t5_flux_beach_seed_45.png" and files2["x1_y1_clip_t5_flux_beach_seed_45.png"].startswith("3|45|on the beach|")
+
+
+def test_embed_export_host_logic_matches_reference_literals(tmp_path):
+    """scripts/test/test_mllama_t5_decoder_flux_embed.py:133-206, ..._embed_multi_image.py:165-180, ..._embed_multi_image_batch.py:145-177."""
+    import io
+    import json
+
+    import torch
+    from scripts.test import test_mllama_t5_decoder_flux_embed as emb
+    from scripts.test import test_mllama_t5_decoder_flux_embed_multi_image as mi
+    from scripts.test import test_mllama_t5_decoder_flux_embed_multi_image_batch as mib
+    from scripts.test import test_mllama_t5_decoder_flux_multi_image_input_embed as txt
+    from scripts.test.test_mllama_t5_decoder_flux_multi_image import build_messages
+
+    # listing: only regular files with the suffixes, directory order
+    for n in ["a.png", "b.jpg", "c.jpeg", "a.json", "task.1.json"]:
+        (tmp_path / n).write_text("{}")
+    (tmp_path / "d.png").mkdir()
+    assert sorted(os.path.basename(u) for u in emb.list_inputs(str(tmp_path), (".png", ".jpg"))) == ["a.png", "b.jpg"]
+    assert sorted(os.path.basename(u) for u in emb.list_inputs(str(tmp_path), (".json",))) == ["a.json", "task.1.json"]
+    assert emb.stem("/x/y/task.1.json") == "task" and emb.sidecar_json("/x/y/a.png") == "/x/y/a.json"
+    assert emb.sidecar_json("/x.d/a.png") == "/x.json"          # the reference cuts the WHOLE path at its first dot (:191)
+
+    # word parts: reference :165-170 evaluated by hand on CoBSAT-style inputs ("white: " loses ": ")
+    assert mi.word_texts(["white: ", "blue: ", "red: "]) == ["Word 1: white, ", "\n\nWord 2: blue, ", "\n\nWord 3: red, "]
+    msgs = build_messages("Q", ["w.jpg", "b.jpg"], mi.word_texts(["white: ", "blue: ", "red: "]), question_in_chat=True, max_pixels=65536)
+    assert msgs[0] == {"role": "system", "content": "You are a helpful assistant."}
+    assert msgs[1]["content"] == [{"type": "text", "text": "Q"}, {"type": "text", "text": "Word 1: white, "},
+                                  {"type": "image", "image": "w.jpg", "max_pixels": 65536}, {"type": "text", "text": "\n\nWord 2: blue, "},
+                                  {"type": "image", "image": "b.jpg", "max_pixels": 65536}, {"type": "text", "text": "\n\nWord 3: red, "}]
+    assert mi.remap_image_paths(["/old/root/cobsat/datasets/color_car/white_car.jpg"], "/data") == ["/data/cobsat/datasets/color_car/white_car.jpg"]
+    assert mi.remap_image_paths(["/p/a.jpg"], None) == ["/p/a.jpg"]
+
+    # batch windows: fixed windows over the listing, finished tasks drop out, windows do not refill
+    urls = [f"t{i}.json" for i in range(5)]
+    assert mib.batches(urls, 2, lambda u: u in ("t1.json", "t2.json", "t3.json")) == [["t0.json"], [], ["t4.json"]]
+
+    # the two files: torch.save bytes of the CPU tensor, json = input json + generated_text + prompt, indent=4, key order kept
+    e = torch.arange(12, dtype=torch.bfloat16).reshape(3, 4)
+    out = tmp_path / "out"
+    out.mkdir()
+    p_embed, p_json = emb.save_embed(str(out), "task", e, {"text_inputs": ["a: "], "image_inputs": []}, "Create an image", "P")
+    assert (p_embed, p_json) == (f"{out}/task.pth", f"{out}/task.json")
+    back = torch.load(io.BytesIO(open(p_embed, "rb").read()))
+    assert back.dtype == torch.bfloat16 and torch.equal(back, e)
+    assert open(p_json).read() == json.dumps({"text_inputs": ["a: "], "image_inputs": [], "generated_text": "Create an image", "prompt": "P"}, indent=4)
+
+    # text-only driver: cut / zero-pad to run.max_tokens (reference ..._multi_image_input_embed.py:258-264)
+    t = torch.ones(1, 5, 3)
+    assert txt.fit_tokens(t, None) is t and txt.fit_tokens(t, 5) is t and txt.fit_tokens(t, 3).shape == (1, 3, 3)
+    padded = txt.fit_tokens(t, 8)
+    assert padded.shape == (1, 8, 3) and torch.equal(padded[:, :5], t) and torch.count_nonzero(padded[:, 5:]) == 0

@@ -225,3 +225,32 @@ def test_from_pretrained_local_diffusers_directory(hip, tmp_path):
     os_remove.unlink()
     with pytest.raises(KeyError):
         FluxPipelineRewritePrompt.from_pretrained(str(tmp_path), max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+
+
+def test_seeded_synthetic_weights_do_not_depend_on_the_allocation(hip):
+    """td_flux_init_random / td_vae_init_random / td_qwen2_init_random(seed): the same seed gives the same weights wherever the
+    arena landed.  Two tiny pipelines (transformer + VAE) and two decoder engines alive at once -- hence at different
+    addresses -- must give equal outputs on equal inputs (the norm weights used to mix the device pointer into their seed, so a
+    driver run twice in one process drew a different synthetic checkpoint the second time)."""
+    from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
+    from thinkdiff.models.flux_transformer import FluxTransformerConfig
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    cfg = FluxTransformerConfig(num_layers=1, num_single_layers=2, num_attention_heads=4, joint_attention_dim=512, pooled_projection_dim=256)
+    pipes = [FluxPipelineRewritePrompt.from_random(cfg, seed=3, max_img_tokens=256, max_txt_tokens=64, max_steps=8) for _ in range(2)]
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(1, 40, 512, generator=g).bfloat16().cuda()
+    pool = torch.randn(1, 256, generator=g).bfloat16().cuda()
+    lat = torch.randn(1, 16 * 16, 64, generator=g).bfloat16().cuda()
+    imgs = [p(prompt_embeds=pe, pooled_prompt_embeds=pool, height=256, width=256, num_inference_steps=2, guidance_scale=3.5,
+              latents=lat.clone(), output_type="pt").images for p in pipes]
+    torch.cuda.synchronize()
+    assert torch.equal(imgs[0], imgs[1])
+    tc = Qwen2VLTextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, intermediate_size=1024, vocab_size=1024)
+    engines = [Qwen2VLTextEngine(tc, max_model_len=128) for _ in range(2)]
+    ids = torch.randint(0, 1024, (37,), generator=g).to(torch.int32)
+    hs = []
+    for e in engines:
+        e.init_random(5)
+        hs.append(e.forward(e.text_position_ids(37), ids, None, 0, True, True))
+    torch.cuda.synchronize()
+    assert torch.equal(hs[0][0], hs[1][0]) and torch.equal(hs[0][1], hs[1][1])

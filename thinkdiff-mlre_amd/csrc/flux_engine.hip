@@ -517,7 +517,7 @@ int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream) {
   TD_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
   for (const Slot& s : f->slots)
     if (s.count == 128 && s.name.find(".norm_") != std::string::npos)
-      TD_TRY(td_fill_normal_bf16(s.ptr, s.count, seed ^ (uint64_t)(uintptr_t)s.ptr, 0.1f, 1.0f, stream));
+      TD_TRY(td_fill_normal_bf16(s.ptr, s.count, seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(s.ptr - f->arena + 1)), 0.1f, 1.0f, stream));
   return TD_OK;
 }
 

@@ -247,7 +247,7 @@ int td_qwen2_init_random(td_qwen2* f, uint64_t seed, float std, void* stream) {
   TDQ_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
   for (const QSlot& s : f->slots)
     if (s.name.find("layernorm.weight") != std::string::npos || s.name == "model.norm.weight")
-      TDQ_TRY(td_fill_normal_bf16(s.ptr, s.count, seed ^ (uint64_t)(uintptr_t)s.ptr, 0.05f, 1.0f, stream));
+      TDQ_TRY(td_fill_normal_bf16(s.ptr, s.count, seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(s.ptr - f->arena + 1)), 0.05f, 1.0f, stream));
   return TD_OK;
 }
 

@@ -259,7 +259,7 @@ int td_vae_init_random(td_vae* f, uint64_t seed, float std, void* stream) {
   for (const VSlot& s : f->slots) {
     const bool norm_w = s.name.find("norm") != std::string::npos && s.name.find(".weight") != std::string::npos;
     const int64_t n = s.kind == 1 ? (int64_t)s.cout * 9 * s.cin_pad : s.count;   // padded output rows stay zero
-    TDV_TRY(td_fill_normal_bf16(s.ptr, n, seed ^ (uint64_t)(uintptr_t)s.ptr, norm_w ? 0.05f : std, norm_w ? 1.0f : 0.0f, stream));
+    TDV_TRY(td_fill_normal_bf16(s.ptr, n, seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(s.ptr - f->arena + 1)), norm_w ? 0.05f : std, norm_w ? 1.0f : 0.0f, stream));
   }
   // padded input channels of conv_in must see zero weights regardless (their activations are zero anyway)
   return TD_OK;
