@@ -83,6 +83,11 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
                       int64_t ldkv, int64_t kv_bstride, void* o, int64_t ldo, int64_t o_bstride,
                       int batch, int Sq, int Skv, int Hq, int Hkv, int head_dim, float scale,
                       int causal, void* stream);
+/* Packed variable-length form (the vision towers' cu_seqlens, [ext] Qwen2VisionTransformerPretrainedModel.forward: full attention
+ * inside each image / frame): q, k, v, o are [total rows, ld] with segment b = rows [seg_starts[b], seg_starts[b+1]); seg_starts is a
+ * DEVICE int32[n_seg + 1]; max_len = the longest segment (sizes the grid).  One launch for all segments, no mask across them. */
+int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
+                             const int* seg_starts, int n_seg, int max_len, int Hq, int Hkv, float scale, void* stream);
 /* Selects the kernel structure td_attention_bf16 launches: 0 = shipped (joint attention with more (query tile, head) items
  * than CUs runs as one round of persistent workgroups over equal KV-tile ranges; the first such call on a device allocates a
  * 35 MB hand-off workspace, so make it before capturing into a hipGraph), 1 = one workgroup per item for every shape, 2 = the
@@ -317,7 +322,7 @@ int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache ro
 int td_qwen2_slot_capacity(const td_qwen2* f);
 /* copy the first `len` cache rows of sequence src to sequence dst (compaction when a sequence finishes) */
 int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream);
-/* One new token for each of the sequences in slots 0..B-1 (B <= 16) in one pass over the weights: token_ids int32[B],
+/* One new token for each of the sequences in slots 0..B-1 (B <= 64) in one pass over the weights: token_ids int32[B],
  * position_ids int32[3,B] (device); cache_pos[b] = tokens already cached for sequence b (HOST ints); hidden_out bf16[B,hidden],
  * logits bf16[B,vocab] (either may be NULL). */
 int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,

@@ -150,3 +150,32 @@ def test_attention_strided_output(hip):
     torch.cuda.synchronize()
     _check(cat[:, :, :H * 128], _ref(qkv[:, :, :256], qkv[:, :, 256:512], qkv[:, :, 512:], H, H, False))
     assert torch.count_nonzero(cat[:, :, H * 128:]) == 0
+
+
+def test_packed_variable_length_segments(hip):
+    """td_attention_varlen_bf16 (the vision towers' cu_seqlens): one launch over packed segments of very different lengths
+    equals full attention run inside each segment on its own; nothing leaks across segment borders."""
+    H = 2
+    lens = [300, 1, 64, 257, 880, 31]
+    S = sum(lens)
+    g = torch.Generator().manual_seed(21)
+    qkv = torch.randn(S, 3 * H * 128, generator=g).bfloat16()
+    d = qkv.cuda()
+    starts = torch.tensor([sum(lens[:i]) for i in range(len(lens) + 1)], dtype=torch.int32).cuda()
+    out = hip.attention_padded_varlen(d, H, 128 ** -0.5, starts, max(lens))
+    torch.cuda.synchronize()
+    W = H * 128
+    r0 = 0
+    for n in lens:
+        c = qkv[r0:r0 + n][None]
+        ref = _ref(c[:, :, :W], c[:, :, W:2 * W], c[:, :, 2 * W:], H, H, False)
+        _check(out[r0:r0 + n][None], ref)
+        alone = hip.attention_padded(d[r0:r0 + n], H, 128 ** -0.5)
+        torch.cuda.synchronize()
+        assert _rel_close(out[r0:r0 + n], alone)
+        r0 += n
+
+
+def _rel_close(a, b, tol=2.0 ** -7):
+    a, b = a.float().cpu(), b.float().cpu()
+    return bool((a - b).abs().max() <= tol * b.abs().max())

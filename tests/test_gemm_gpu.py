@@ -145,10 +145,13 @@ def test_linear_tile_288x192(hip, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 3584, 18944), (1, 4608, 3584), (2, 152064, 256), (3, 1024, 3072), (5, 40, 1408), (8, 3072, 768), (1, 8, 64),
-                                   (16, 3584, 18944), (13, 4608, 3584), (9, 37888, 1536), (6, 48, 64), (16, 151936, 1536)])
+                                   (16, 3584, 18944), (13, 4608, 3584), (9, 37888, 1536), (6, 48, 64), (16, 151936, 1536),
+                                   (17, 4608, 3584), (32, 1536, 8960), (33, 3584, 18944), (48, 151936, 1536), (64, 17920, 1536), (40, 48, 64),
+                                   (50, 32784, 128), (64, 1536, 1536)])
 @pytest.mark.parametrize("mode", ["bias", "act", "gate_res", "none"])
 def test_skinny_m_weight_stream_kernel(hip, M, N, K, mode):
-    """M <= 8 routes to csrc/gemv_bf16.hip (td_gemv_bf16_kernel): same epilogue semantics as the tile kernel."""
+    """M <= 64 routes to csrc/gemv_bf16.hip (dot-product stream up to 4 rows, matrix-core stream with 1-4 activation blocks
+    above; two weight blocks per workgroup from 2048 blocks on, odd block counts included): the tile kernel's epilogue semantics."""
     g = torch.Generator().manual_seed(M * 11 + N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()

@@ -148,6 +148,32 @@ def test_batched_decode_equals_one_sequence_at_a_time(hip):
         assert o["token_ids"] == ref["token_ids"] and _rel(o["hidden_states"], ref["hidden_states"]) < 5e-3
 
 
+def test_batched_decode_of_forty_sequences(hip):
+    """More than 16 sequences per pass over the weights (td_gemv_mfma_kernel with 3 activation blocks, gated and split-output
+    forms included): 40 requests of different lengths, teacher-forced, against generate() per request."""
+    from thinkdiff.models.qwen2_vl import SamplingParams
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=12)
+    e = _engine(cfg, sd, max_len=8192)
+    g = torch.Generator().manual_seed(6)
+    B = 40
+    lens = [5 + (7 * i) % 60 for i in range(B)]
+    gens = [1 + (5 * i) % 9 for i in range(B)]
+    reqs = [{"prompt_token_ids": torch.randint(0, cfg.vocab, (n,), generator=g).tolist()} for n in lens]
+    forced = [torch.randint(0, cfg.vocab, (k,), generator=g).tolist() for k in gens]
+    sp = SamplingParams(max_tokens=9, min_tokens=9, ignore_eos=True)
+    single = [e.generate(r["prompt_token_ids"], sp, forced_output_ids=f) for r, f in zip(reqs, forced)]
+    single = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in single]
+    e.set_slots(64)
+    assert e.slot_len == 128
+    batch = e.generate_batch(reqs, sp, forced_output_ids=forced)
+    torch.cuda.synchronize()
+    for a, b, k in zip(single, batch, gens):
+        assert b["token_ids"] == a["token_ids"] and b["hidden_states"].shape == (k, cfg.hidden)
+        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 5e-3
+        assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
+
+
 def test_get_embed_batches_requests(hip):
     """get_embed over several requests with max_num_seqs > 1 runs them through generate_batch: same aligner inputs as one
     request at a time (teacher-forced)."""

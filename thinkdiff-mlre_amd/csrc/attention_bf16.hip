@@ -67,7 +67,7 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 // accumulator zeroing.  Here every per-lane LDS address lives in a register for the whole kernel (8 for the K row reads,
 // 8 for the V transposed reads; k-block / k-step / tile-slot parts are instruction immediates).
 // ---------------------------------------------------------------------------------------------
-template <bool CAUSAL, int NWAVES, bool BIAS = false>
+template <bool CAUSAL, int NWAVES, bool BIAS = false, bool VARLEN = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(const TdAttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1]
@@ -88,11 +88,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   const bf16_t* Kb = p.K + (size_t)batch * p.kv_bstride;
   const bf16_t* Vb = p.V + (size_t)batch * p.kv_bstride;
   bf16_t* Ob = p.O + (size_t)batch * p.o_bstride;
+  int Sq = p.Sq, Skv = p.Skv, c_off = p.causal_offset;
+  if constexpr (VARLEN) {
+    // packed segments (the vision towers' cu_seqlens): segment `batch` = rows [seg_starts[b], seg_starts[b+1]) of q, k, v and o,
+    // full attention inside it; the grid is sized for the longest segment, workgroups past this one's rows leave at once
+    const int r0 = p.seg_starts[batch];
+    Sq = Skv = p.seg_starts[batch + 1] - r0;
+    if (qblk * (NWAVES * Q_WAVE) >= Sq) return;
+    Qb += (size_t)r0 * p.ldq; Kb += (size_t)r0 * p.ldkv; Vb += (size_t)r0 * p.ldkv; Ob += (size_t)r0 * p.ldo;
+  }
 
-  const unsigned q_bytes = (unsigned)(((long long)(p.Sq - 1) * p.ldq + p.Hq * D) * 2);
+  const unsigned q_bytes = (unsigned)(((long long)(Sq - 1) * p.ldq + p.Hq * D) * 2);
   // batched KV-cached decode: sequence `batch` has its own cache length (causal instantiation only, so the joint-attention
   // instruction stream of FLUX is untouched); keys visible to query row q: key <= q + (Skv - Sq)
-  int Skv = p.Skv, c_off = p.causal_offset;
   if constexpr (CAUSAL) {
     if (p.kv_lens) { Skv = p.kv_lens[batch]; c_off = Skv - p.Sq; }
   }
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 
   int nt = (Skv + KV_TILE - 1) / KV_TILE;
   if (CAUSAL) {
-    const int last_q = min(p.Sq, (qblk + 1) * NWAVES * Q_WAVE) - 1 + c_off;
+    const int last_q = min(Sq, (qblk + 1) * NWAVES * Q_WAVE) - 1 + c_off;
     nt = min(nt, last_q / KV_TILE + 1);
   }
 
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   const float l_tot = half_swap_sum(l_run);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
-  if (q < p.Sq) {
+  if (q < Sq) {
     bf16_t* op = Ob + (size_t)q * p.ldo + head * D + 4 * h5;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -654,7 +662,9 @@ int sk_pooled_workspace(int dev, int ranges, hipStream_t stream, char** out) {
     if (e.dev == dev && e.stream == stream && e.ranges >= ranges) { *out = e.ws; return 0; }
   char* w = nullptr;
   TD_CHECK_HIP(hipMalloc((void**)&w, sk_ws_bytes(ranges)));
-  TD_CHECK_HIP(hipMemset(w, 0, SK_HEADER_BYTES));
+  // zeroed ON the launching stream: a null-stream memset is not ordered with a non-blocking stream, and the first persistent
+  // launch of a new stream would race it for the hand-off counters
+  TD_CHECK_HIP(hipMemsetAsync(w, 0, SK_HEADER_BYTES, stream));
   pool.push_back(Entry{dev, stream, ranges, w});
   *out = w;
   return 0;
@@ -707,6 +717,14 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
   if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
   if (p.kv_lens) TD_CHECK_ARG(p.causal && !p.bias, "td_attention: per-sequence kv lengths exist for the causal kernel only");
+  if (p.seg_starts) {   // packed segments: plain grid over (query tiles of the longest segment, heads, segments)
+    TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && p.Sq == p.Skv, "td_attention(varlen): full attention inside each segment only (no mask, bias or cache lengths)");
+    static std::atomic<unsigned long long> a6{0};
+    if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, true>, lds, a6, dev)) return e;
+    hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, true>), grid, dim3(NW * 64), lds, stream, q);
+    TD_CHECK_LAUNCH();
+    return 0;
+  }
 
   // joint attention with more workgroups than CUs: one round of persistent workgroups over equal (item, KV tile) ranges.
   // variant 1 = the one-workgroup-per-item kernel for every shape (in-process A/B); variant 2 = stream-K without the XCD remap.

@@ -94,6 +94,17 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
   return td_attn_launch(p, (hipStream_t)stream);
 }
 
+int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
+                             const int* seg_starts, int n_seg, int max_len, int Hq, int Hkv, float scale, void* stream) {
+  TD_CHECK_ARG(seg_starts && n_seg > 0 && max_len > 0, "td_attention_varlen: empty segment list");
+  TdAttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o;
+  p.batch = n_seg; p.Sq = max_len; p.Skv = max_len; p.Hq = Hq; p.Hkv = Hkv; p.head_dim = 128;
+  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo;
+  p.scale = scale; p.causal = 0; p.causal_offset = 0; p.variant = 1; p.seg_starts = seg_starts;
+  return td_attn_launch(p, (hipStream_t)stream);
+}
+
 int td_norm_rows_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int D, int rms, float eps,
                       const void* w, int split, const void* shiftA, const void* scaleA,
                       const void* shiftB, const void* scaleB, void* stream) {

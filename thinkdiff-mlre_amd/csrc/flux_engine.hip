@@ -255,6 +255,7 @@ int alloc_workspace(td_flux* f) {
     return TD_ERR_HIP;
   }
   (void)hipMemset(f->ws, 0, (size_t)total);
+  (void)hipDeviceSynchronize();   // the handle may be used from any stream next; a null-stream memset is not ordered with non-blocking streams
   int64_t o = 0;
   for (auto& r : reqs) {
     *r.p = f->ws + o;

@@ -606,12 +606,12 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     // output-channel tile: 64, 128 (the 128-channel 1024^2 / 512^2 layers of the VAE: a 256-wide tile would be half empty) or 256
     return p.N <= 64 ? launch_cfg<8, 1, true>(p, stream) : p.N <= 128 ? launch_cfg<8, 2, true>(p, stream) : launch_cfg<8, 4, true>(p, stream);
   }
-  // M <= 16 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode of up to 16 sequences, embedders, lm_head)
+  // M <= 64 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode of up to 64 sequences, embedders, lm_head)
   if (p.glu_I) {
-    TD_CHECK_ARG(p.M <= 16 && p.g_M == 0 && !p.fp8 && !p.out_f32 && p.conv_H == 0, "td_gemm: the gated form exists for the skinny-M kernels only (M <= 16)");
+    TD_CHECK_ARG(p.M <= 64 && p.g_M == 0 && !p.fp8 && !p.out_f32 && p.conv_H == 0, "td_gemm: the gated form exists for the skinny-M kernels only (M <= 64)");
     return td_gemv_launch(p, stream);
   }
-  if (p.M <= 16 && p.g_M == 0 && !p.fp8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0) return td_gemv_launch(p, stream);
+  if (p.g_M == 0 && !p.fp8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
   if (p.fp8) {
     TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,

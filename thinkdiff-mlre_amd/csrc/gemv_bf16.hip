@@ -1,4 +1,4 @@
-// Skinny-M Linear for gfx950: y[M<=16, N] = epilogue(x[M,K] . W[N,K]^T), the weight-streaming case of the hot path --
+// Skinny-M Linear for gfx950: y[M<=64, N] = epilogue(x[M,K] . W[N,K]^T), the weight-streaming case of the hot path --
 // KV-cached Qwen2-VL decode (one token against 7.6 B parameters: SURVEY.md 8a row A7, HBM roofline), the pooled / timestep
 // embedders of FLUX, lm_head.  The MFMA tile kernel launches N/256 workgroups here (14 for down_proj) and leaves the
 // chip idle; this kernel is a plain HBM stream:
@@ -126,98 +126,155 @@ __global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParam
   else p.C[(size_t)m * p.ldc + n] = f2bf(v);
 }
 
-// ---- 4 < M <= 16: the same weight stream on the matrix core ---------------------------------------------------------
+// ---- 4 < M <= 64: the same weight stream on the matrix core ---------------------------------------------------------
 // With more activation rows the dot-product form re-reads x from L2 MR times per weight chunk (at M = 16 x traffic is 8x the
-// weight traffic and the kernel stops scaling).  Here a workgroup owns 16 weight rows, its 8 waves split K in 64-element steps,
-// and every step is two v_mfma_f32_16x16x32_bf16 with the weight rows as the A operand and the (<= 16) activation rows as the
-// B operand -- both fragments are loaded straight from global memory in MFMA operand layout (lane = row, 16 B of k), so x
-// traffic equals weight traffic and there is no VALU work in the loop.  Accumulators are reduced across waves through LDS.
+// weight traffic and the kernel stops scaling).  Here a workgroup owns NR blocks of 16 weight rows, its 8 waves split K in
+// 64-element steps, and every step is two v_mfma_f32_16x16x32_bf16 per (weight block, activation block) with the weight rows as
+// the A operand and 16 activation rows as the B operand -- both fragments are loaded straight from global memory in MFMA operand
+// layout (lane = row, 16 B of k), so there is no VALU work in the loop.  MB = ceil(M / 16) activation blocks share every weight
+// fragment (batched decode of up to 64 sequences: one pass over the weights); x comes from L2, MB / NR bytes per weight byte.
+// Accumulators are reduced across waves through LDS, one weight block at a time.
 constexpr int MW = 8;   // waves per workgroup (K split)
 
+template <int MB, int NR>
 __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParams p) {
-  __shared__ float red[MW][64][4];
+  __shared__ float red[MW][MB][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  // gated mode: rows 0-7 = gate rows 8b..8b+7, rows 8-15 = the matching up rows
-  const int wr_ = p.glu_I ? (blockIdx.x * 8 + (r & 7) + (r >> 3) * p.glu_I) : min(n0 + r, p.N - 1);
-  const bf16_t* wrow = p.W + (size_t)wr_ * p.K + 8 * g;
-  const bf16_t* xrow = p.A + (size_t)min(r, p.M - 1) * p.lda + 8 * g;
+  const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;         // 16-row weight blocks of the problem
+  const bf16_t* wrow[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int bid = min((int)blockIdx.x * NR + nr, nblk - 1);
+    // gated mode: rows 0-7 = gate rows 8b..8b+7, rows 8-15 = the matching up rows
+    const int wr_ = p.glu_I ? (bid * 8 + (r & 7) + (r >> 3) * p.glu_I) : bid * 16 + r;
+    wrow[nr] = p.W + (size_t)wr_ * p.K + 8 * g;
+  }
+  const bf16_t* xrow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) xrow[mb] = p.A + (size_t)min(16 * mb + r, p.M - 1) * p.lda + 8 * g;
   const int nk = p.K >> 6;                      // 64-element steps
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[NR][MB];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[nr][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int SF = (MB * NR == 1) ? 2 : 1;    // k-steps in flight per wave: 4 (SF = 2) or 2 NR + 2 MB 16-byte loads per lane
   int s = wid;
-  for (; s + MW < nk; s += 2 * MW) {            // two steps in flight: 4 weight + 4 activation loads per lane
-    const bf16x8_t w0 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64));
-    const bf16x8_t w1 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64 + 32));
-    const bf16x8_t w2 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)(s + MW) * 64));
-    const bf16x8_t w3 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)(s + MW) * 64 + 32));
-    const bf16x8_t x0 = *(const bf16x8_t*)(xrow + (size_t)s * 64);
-    const bf16x8_t x1 = *(const bf16x8_t*)(xrow + (size_t)s * 64 + 32);
-    const bf16x8_t x2 = *(const bf16x8_t*)(xrow + (size_t)(s + MW) * 64);
-    const bf16x8_t x3 = *(const bf16x8_t*)(xrow + (size_t)(s + MW) * 64 + 32);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3, x3, acc, 0, 0, 0);
-  }
-  if (s < nk) {
-    const bf16x8_t w0 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64));
-    const bf16x8_t w1 = __builtin_nontemporal_load((const bf16x8_t*)(wrow + (size_t)s * 64 + 32));
-    const bf16x8_t x0 = *(const bf16x8_t*)(xrow + (size_t)s * 64);
-    const bf16x8_t x1 = *(const bf16x8_t*)(xrow + (size_t)s * 64 + 32);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc, 0, 0, 0);
-  }
+  for (; s + (SF - 1) * MW < nk; s += SF * MW) {
+    bf16x8_t w[SF][NR][2], x[SF][MB][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) red[wid][lane][i] = acc[i];
-  __syncthreads();
-  if (wid != 0) return;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < SF; ++f) {
+      const size_t k0 = (size_t)(s + f * MW) * 64;
 #pragma unroll
-  for (int w = 0; w < MW; ++w)
+      for (int nr = 0; nr < NR; ++nr) {
+        w[f][nr][0] = __builtin_nontemporal_load((const bf16x8_t*)(wrow[nr] + k0));
+        w[f][nr][1] = __builtin_nontemporal_load((const bf16x8_t*)(wrow[nr] + k0 + 32));
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += red[w][lane][i];
-  if (p.glu_I) {   // lanes g = 0,1 hold gate rows 4g+i, their partners 32 lanes up the matching up rows
-    float u[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = __shfl(v[i], (lane + 32) & 63, 64);
-    if (g < 2 && r < p.M) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = rbf(silu_f(rbf(v[i]))) * rbf(u[i]);
-      *(u32x2_t*)(p.C + (size_t)r * p.ldc + blockIdx.x * 8 + 4 * g) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      for (int mb = 0; mb < MB; ++mb) {
+        x[f][mb][0] = *(const bf16x8_t*)(xrow[mb] + k0);
+        x[f][mb][1] = *(const bf16x8_t*)(xrow[mb] + k0 + 32);
+      }
     }
-    return;
-  }
-  // C layout of the MFMA: column (lane & 15) = activation row m, rows 4 (lane >> 4) + i = weight rows n
-  const int m = r, n = n0 + 4 * g;
-  if (m >= p.M || n >= p.N) return;
-  const bool second = p.C2 != nullptr && n >= p.n_split;
-  const int act = second ? p.act2 : p.act;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float y = v[i];
-    if (p.bias) y += bf2f(p.bias[n + i]);
-    if (act != TD_ACT_NONE) y = act_rt(act, rbf(y));
-    else {
-      if (p.gate) y = rbf(y) * bf2f(p.gate[n + i]);
-      if (p.res) y = rbf(y) + bf2f(p.res[(size_t)m * p.ldr + n + i]);
-    }
-    v[i] = y;
+    for (int f = 0; f < SF; ++f)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[nr][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][nr][h], x[f][mb][h], acc[nr][mb], 0, 0, 0);
   }
-  const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-  if (second) *(u32x2_t*)(p.C2 + (size_t)m * p.ldc2 + (n - p.n_split)) = o;
-  else *(u32x2_t*)(p.C + (size_t)m * p.ldc + n) = o;
+  if (SF == 2 && s < nk) {
+    const size_t k0 = (size_t)s * 64;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bf16x8_t w0 = __builtin_nontemporal_load((const bf16x8_t*)(wrow[0] + k0 + 32 * h));
+      const bf16x8_t x0 = *(const bf16x8_t*)(xrow[0] + k0 + 32 * h);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[0][0], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    if (nr) __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wid][mb][lane][i] = acc[nr][mb][i];
+    __syncthreads();
+    const int bid = blockIdx.x * NR + nr;
+    if (wid >= MB || bid >= nblk) continue;       // wave mb finishes activation block mb of this weight block
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < MW; ++w)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += red[w][wid][lane][i];
+    // C layout of the MFMA: column (lane & 15) = activation row, rows 4 (lane >> 4) + i = weight rows
+    const int m = 16 * wid + r;
+    if (p.glu_I) {   // lanes g = 0,1 hold gate rows 4g+i, their partners 32 lanes up the matching up rows
+      float u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i] = __shfl(v[i], (lane + 32) & 63, 64);
+      if (g < 2 && m < p.M) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = rbf(silu_f(rbf(v[i]))) * rbf(u[i]);
+        *(u32x2_t*)(p.C + (size_t)m * p.ldc + bid * 8 + 4 * g) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      }
+      continue;
+    }
+    const int n = bid * 16 + 4 * g;
+    if (m >= p.M) continue;
+    const bool second = p.C2 != nullptr && n >= p.n_split;
+    const int act = second ? p.act2 : p.act;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float y = v[i];
+      if (p.bias) y += bf2f(p.bias[n + i]);
+      if (act != TD_ACT_NONE) y = act_rt(act, rbf(y));
+      else {
+        if (p.gate) y = rbf(y) * bf2f(p.gate[n + i]);
+        if (p.res) y = rbf(y) + bf2f(p.res[(size_t)m * p.ldr + n + i]);
+      }
+      v[i] = y;
+    }
+    const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    if (second) *(u32x2_t*)(p.C2 + (size_t)m * p.ldc2 + (n - p.n_split)) = o;
+    else *(u32x2_t*)(p.C + (size_t)m * p.ldc + n) = o;
+  }
+}
+
+template <int MB>
+void launch_mfma(const TdGemmParams& p, hipStream_t stream) {
+  const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;
+  // two weight blocks per workgroup halve the x re-reads from L2; only where the grid still oversubscribes the chip
+  if (MB > 1 && nblk >= 2048) hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 2>), dim3((nblk + 1) / 2), dim3(MW * 64), 0, stream, p);
+  else hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 1>), dim3(nblk), dim3(MW * 64), 0, stream, p);
+}
+
+void launch_mfma_rows(const TdGemmParams& p, hipStream_t stream) {
+  if (p.M <= 16) launch_mfma<1>(p, stream);
+  else if (p.M <= 32) launch_mfma<2>(p, stream);
+  else if (p.M <= 48) launch_mfma<3>(p, stream);
+  else launch_mfma<4>(p, stream);
 }
 
 }  // namespace
 
+// shapes the matrix-core weight stream takes (td_gemm_launch asks before routing 16 < M <= 64 here)
+bool td_gemv_mfma_ok(const TdGemmParams& p) {
+  return p.K % 64 == 0 && p.N % 16 == 0 && p.ldc % 4 == 0 && p.lda % 8 == 0 && (!p.C2 || (p.ldc2 % 4 == 0 && p.n_split % 4 == 0));
+}
+
+
 int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
-  TD_CHECK_ARG(p.M >= 1 && p.M <= 16 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 16, N %% 4 == 0, K %% 8 == 0");
+  TD_CHECK_ARG(p.M >= 1 && p.M <= 64 && p.N % R == 0 && p.K % 8 == 0 && p.lda % 8 == 0, "td_gemv: needs M <= 64, N %% 4 == 0, K %% 8 == 0");
   TD_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.W) % 16 == 0, "td_gemv: operands must be 16-byte aligned");
   if (p.glu_I) {
     TD_CHECK_ARG(p.N == p.glu_I && p.glu_I % 8 == 0 && !p.bias && !p.gate && !p.res && !p.C2 && p.act == TD_ACT_NONE && p.ldc % 4 == 0,
                  "td_gemv(glu): N must equal glu_I (multiple of 8), no bias / gate / residual / split");
-    if (p.M > 4 && p.K % 64 == 0) hipLaunchKernelGGL(td_gemv_mfma_kernel, dim3(p.glu_I / 8), dim3(MW * 64), 0, stream, p);
+    TD_CHECK_ARG(p.M <= 16 || p.K % 64 == 0, "td_gemv(glu): more than 16 rows need K %% 64 == 0");
+    if (p.M > 4 && p.K % 64 == 0) launch_mfma_rows(p, stream);
     else if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
     else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
     else if (p.M <= 4) hipLaunchKernelGGL(td_gemv_bf16_kernel<4>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
@@ -226,11 +283,12 @@ int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_LAUNCH();
     return 0;
   }
-  if (p.M > 4 && p.K % 64 == 0 && p.N % 16 == 0 && p.ldc % 4 == 0 && (!p.C2 || (p.ldc2 % 4 == 0 && p.n_split % 4 == 0)) && (!p.res || p.ldr % 1 == 0)) {
-    hipLaunchKernelGGL(td_gemv_mfma_kernel, dim3(p.N / 16), dim3(MW * 64), 0, stream, p);
+  if (p.M > 4 && td_gemv_mfma_ok(p)) {
+    launch_mfma_rows(p, stream);
     TD_CHECK_LAUNCH();
     return 0;
   }
+  TD_CHECK_ARG(p.M <= 16, "td_gemv: more than 16 rows need the matrix-core form (K %% 64, N %% 16, ldc %% 4 == 0)");
   const dim3 grid(p.N / R), block(THREADS);
   if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, grid, block, 0, stream, p);
   else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, grid, block, 0, stream, p);

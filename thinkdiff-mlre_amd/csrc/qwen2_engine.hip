@@ -62,7 +62,7 @@ void q_add(td_qwen2* f, const std::string& name, bf16_t* p, int64_t n) {
   f->slots.push_back({name, p, n});
 }
 
-constexpr int MAX_BATCH = 16;   // td_gemv_bf16_kernel streams the weights once for up to 16 rows
+constexpr int MAX_BATCH = 64;   // td_gemv_mfma_kernel streams the weights once for up to 64 rows
 
 struct IntPack { int v[2 * MAX_BATCH]; };
 __global__ void td_set_ints_kernel(int* dst, IntPack vals, int n) {
@@ -131,6 +131,7 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
   if (ws_rows < slot_len) ws_rows = slot_len;
   const int max_tokens = slot_len * n_slots;
   TD_CHECK_ARG(cfg->head_dim == 128, "td_qwen2_create: head_dim must be 128");
+  TD_CHECK_ARG((long long)max_tokens * 2 * cfg->num_kv_heads * 128 < (1ll << 31), "td_qwen2_create: %d cache rows of %d elements exceed the 32-bit row offsets of the decode step", max_tokens, 2 * cfg->num_kv_heads * 128);
   TD_CHECK_ARG(cfg->hidden % 512 == 0 && cfg->intermediate % 64 == 0, "td_qwen2_create: hidden %% 512 and intermediate %% 64 must be 0");
   TD_CHECK_ARG(cfg->num_heads % cfg->num_kv_heads == 0, "td_qwen2_create: heads must be a multiple of kv heads");
   TD_CHECK_ARG(cfg->mrope_section[0] + cfg->mrope_section[1] + cfg->mrope_section[2] == 64, "td_qwen2_create: mrope sections must sum to 64");
@@ -207,6 +208,7 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
     return TD_ERR_HIP;
   }
   (void)hipMemset(f->ws, 0, (size_t)total);
+  (void)hipDeviceSynchronize();   // the handle may be used from any stream next; a null-stream memset is not ordered with non-blocking streams
   int64_t o = 0;
   for (auto& r : reqs) { *r.p = f->ws + o; o += (r.bytes + 255) & ~int64_t(255); }
   *out = f;
@@ -375,12 +377,12 @@ int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream) {
   return TD_OK;
 }
 
-// One new token for each of the sequences in slots 0 .. B-1 (B <= 16): token_ids int32[B], position_ids int32[3,B] (device),
+// One new token for each of the sequences in slots 0 .. B-1 (B <= 64): token_ids int32[B], position_ids int32[3,B] (device),
 // cache_pos[b] = tokens already in slot b (HOST ints).  hidden_out bf16[B,hidden], logits bf16[B,vocab] (either may be NULL).
 int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
                           void* hidden_out, void* logits, void* stream) {
   TD_CHECK_ARG(f && token_ids && position_ids && cache_pos, "td_qwen2_decode_batch: null argument");
-  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots)", B, MAX_BATCH, f->n_slots);
+  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && B <= f->ws_rows, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots, %d workspace rows)", B, MAX_BATCH, f->n_slots, f->ws_rows);
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
@@ -392,7 +394,7 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
     ip.v[MAX_BATCH + b] = (b * f->slot_len + cache_pos[b]) * KVW;       // its cache row (elements)
     max_len = cache_pos[b] + 1 > max_len ? cache_pos[b] + 1 : max_len;
   }
-  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(64), 0, s, f->ibuf, ip, 2 * MAX_BATCH);
+  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, f->ibuf, ip, 2 * MAX_BATCH);
   const int* kv_lens = f->ibuf;
   const int* row_off = f->ibuf + MAX_BATCH;
 

@@ -40,6 +40,7 @@ struct TdGemmParams {
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);
 // weight-streaming form for M <= 8 (td_gemm_launch routes to it; csrc/gemv_bf16.hip)
 int td_gemv_launch(const TdGemmParams& p, hipStream_t stream);
+bool td_gemv_mfma_ok(const TdGemmParams& p);   // shapes the matrix-core weight stream takes for 16 < M <= 64
 // 0: 256x256 (td_gemm_bf16_nt_kernel<8,4>), 1: 256x64, 2: 32x256, 3: 288x192 (<9,3>)
 int td_gemm_config_id(int M, int N, int K);
 
@@ -62,6 +63,8 @@ struct TdAttnParams {
   const float* bias = nullptr;
   // optional per-batch cache length (device int[batch], causal kernel): sequence b attends keys [0, kv_lens[b]); Skv = the largest
   const int* kv_lens = nullptr;
+  // optional packed segments (device int[batch + 1], non-causal): segment b = rows [seg_starts[b], seg_starts[b+1]) of q/k/v/o; Sq = Skv = the longest
+  const int* seg_starts = nullptr;
   // optional hand-off workspace of the persistent (stream-K) joint-attention kernel: td_attn_streamk_ws_bytes() bytes, zeroed
   // once by its owner, not shared by launches that may run concurrently (null: a per-(device, stream) one is created inside)
   void* sk_ws = nullptr;

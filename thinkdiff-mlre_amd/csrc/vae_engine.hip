@@ -168,6 +168,7 @@ int td_vae_create(const TdVaeConfig* cfg, int max_latent_h, int max_latent_w, td
   hipError_t e = hipMalloc((void**)&f->arena, (size_t)pl.off * 2);
   if (e != hipSuccess) { td_set_error("td_vae_create: weight hipMalloc failed: %s", hipGetErrorString(e)); delete f; return TD_ERR_HIP; }
   (void)hipMemset(f->arena, 0, (size_t)pl.off * 2);   // padded weight rows / channels must be zero
+  (void)hipDeviceSynchronize();   // the handle may be used from any stream next; a null-stream memset is not ordered with non-blocking streams
   for (auto& fx : pl.fix) *fx.first = f->arena + fx.second;
 
   // diffusers state-dict names

@@ -74,6 +74,7 @@ def _declare(L):
         "td_add_rows_bf16": [vp, vp, vp, i32, i32, i32, vp],
         "td_glu_mul_bf16": [vp, vp, i32, i32, i32, vp],
         "td_attention_bias_bf16": [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, vp, vp],
+        "td_attention_varlen_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp],
         "td_rope_half_bf16": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
         "td_vision_rope_table": [vp, i32, i32, f32, vp, vp, vp],
         "td_patchify_bf16": [vp, i32, i32, i32, i32, i32, vp, i32, vp],
@@ -357,6 +358,20 @@ def attention_padded(qkv, H, scale, causal=False, bias=None, out=None):
     assert out.shape == (S, W) and out.is_contiguous()
     check(lib().td_attention_bias_bf16(ptr(qkv), _rows(qkv), ptr(qkv[:, W:]), ptr(qkv[:, 2 * W:]), _rows(qkv), ptr(out), W,
                                        S, S, H, H, float(scale), int(causal), ptr(bias), stream_ptr()))
+    return out
+
+
+def attention_padded_varlen(qkv, H, scale, seg_starts, max_len, out=None):
+    """attention_padded over packed segments in ONE launch: qkv [S, 3*H*128], seg_starts device int32 [n_seg + 1] (row offsets,
+    seg_starts[-1] == S), full attention inside each segment.  max_len = the longest segment."""
+    S = qkv.shape[0]
+    W = H * 128
+    if out is None:
+        out = torch.empty(S, W, dtype=torch.bfloat16, device=qkv.device)
+    assert out.shape == (S, W) and out.is_contiguous()
+    assert seg_starts.dtype == torch.int32 and seg_starts.is_cuda and seg_starts.is_contiguous() and seg_starts.numel() >= 2
+    check(lib().td_attention_varlen_bf16(ptr(qkv), _rows(qkv), ptr(qkv[:, W:]), ptr(qkv[:, 2 * W:]), _rows(qkv), ptr(out), W,
+                                         ptr(seg_starts), seg_starts.numel() - 1, int(max_len), H, H, float(scale), stream_ptr()))
     return out
 
 

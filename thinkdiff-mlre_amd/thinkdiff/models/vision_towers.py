@@ -191,13 +191,17 @@ class HipQwen2VisionTransformer(_Base):
             for _ in range(t):
                 seg.append((a0, a0 + gh * gw))
                 a0 += gh * gw
+        # several frames: one packed variable-length launch per layer instead of one launch per frame
+        starts = torch.tensor([s0 for s0, _ in seg] + [S], dtype=torch.int32).to(self.device) if len(seg) > 1 else None
+        max_len = max(s1 - s0 for s0, s1 in seg)
         for L in self.layers:
             x = _hip.layernorm(h, L["ln1w"], L["ln1b"], 1e-6)
             qkv = _hip.linear(x, L["qkv_w"], L["qkv_b"])
             _hip.rope_half(qkv, 2 * self.H, self.hd, cos, sin)                # q and k heads are adjacent 128-wide slots
-            a = torch.empty(S, self.H * HP, dtype=torch.bfloat16, device=self.device)
-            for s0, s1 in seg:
-                _hip.attention_padded(qkv[s0:s1], self.H, self.hd ** -0.5, out=a[s0:s1])
+            if starts is None:
+                a = _hip.attention_padded(qkv, self.H, self.hd ** -0.5)
+            else:
+                a = _hip.attention_padded_varlen(qkv, self.H, self.hd ** -0.5, starts, max_len)
             h = _hip.linear(a, L["o_w"], L["o_b"], res=h)
             x = _hip.layernorm(h, L["ln2w"], L["ln2b"], 1e-6)
             h = _hip.linear(_hip.linear(x, L["fc1_w"], L["fc1_b"], act=self.act), L["fc2_w"], L["fc2_b"], res=h)

@@ -1,25 +1,31 @@
-"""KV-cached decode step time vs batch (sequences per weight pass), Qwen2-VL-2B and -7B shapes, synthetic weights."""
+"""KV-cached decode step of the Qwen2-VL engines (synthetic weights) against the number of sequences sharing the pass over the
+weights: ms per step and per sequence-token, for the 2B (precompute job) and 7B (ThinkDiff-LVLM) shapes."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "thinkdiff-mlre_amd"))
 from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
 
-for name, tc in (("2B", Qwen2VLTextConfig(hidden_size=1536, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2, intermediate_size=8960, vocab_size=151936, tie_word_embeddings=True)),
-                 ("7B", Qwen2VLTextConfig())):
-    e = Qwen2VLTextEngine(tc, max_model_len=1024, n_slots=16).init_random(0)
-    n0 = 300
-    for b in range(16):
-        e.forward(e.text_position_ids(n0), torch.randint(0, 1000, (n0,), dtype=torch.int32), slot=b)
-    for B in (1, 2, 4, 8, 16):
-        tok = torch.randint(0, 1000, (B,), dtype=torch.int32)
-        for i in range(3):
-            e.decode_batch(tok, [[n0 + i] * B] * 3, [n0 + i] * B)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        N = 30
-        for i in range(N):
-            e.decode_batch(tok, [[n0 + 3 + i] * B] * 3, [n0 + 3 + i] * B)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / N * 1e3
-        print(f"{name} decode batch {B:2d}: {ms:6.3f} ms/step  {B/ms*1e3:7.0f} tokens/s", flush=True)
+shapes = {"2B": Qwen2VLTextConfig(hidden_size=1536, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2, intermediate_size=8960,
+                                  vocab_size=151936, tie_word_embeddings=True),
+          "7B": Qwen2VLTextConfig()}
+which = sys.argv[1:] or ["2B", "7B"]
+CACHE = 300
+for name in which:
+    cfg = shapes[name]
+    e = Qwen2VLTextEngine(cfg, max_model_len=512, n_slots=64, prefill_rows=64 * 320).init_random(0)
+    wbytes = 2 * (cfg.num_hidden_layers * (cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * 128 + cfg.num_attention_heads * 128 * cfg.hidden_size
+                  + 3 * cfg.hidden_size * cfg.intermediate_size) + cfg.vocab_size * cfg.hidden_size)
+    for B in (1, 4, 8, 16, 24, 32, 48, 64):
+        toks = [5] * B
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            N = 24
+            for i in range(N):
+                pos = torch.full((3, B), CACHE + i, dtype=torch.int32)
+                e.decode_batch(toks, pos, [CACHE + i] * B)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / N * 1e3
+        print(f"{name} decode B={B:3d}: {ms:7.3f} ms/step  {ms / B * 1e3:8.1f} us per sequence-token  {wbytes / ms / 1e9:6.2f} TB/s of weights", flush=True)
     del e
+    torch.cuda.empty_cache()
