@@ -239,6 +239,11 @@ int td_rope_half_bf16(void* x, int64_t ldx, int S, int H, int head_stride, int h
 int td_vision_rope_table(const int* pos, int S, int hd, float theta, float* cos_t, float* sin_t, void* stream);
 /* Conv2d(kernel = stride = p) operand: pix [C,H,W] (fp32 if src_f32 else bf16) -> out [(H/p)(W/p), Kpad] bf16, zero padded. */
 int td_patchify_bf16(const void* pix, int src_f32, int C, int H, int W, int p, void* out, int Kpad, void* stream);
+/* Qwen2-VL image preprocessing after the resize ([ext] transformers Qwen2VLImageProcessor rescale / normalize / patchify, which
+ * vLLM runs on the host for thinkdiff/models/mllama_vllm_generate_1.py:543-583): img uint8 [H,W,3] (device) -> out bf16
+ * [(H/patch)(W/patch), Kpad] in the processor's merge-window row order, columns (c, t, py, px); lut fp32 [3,256] = the
+ * processor's own rescale + normalize of every pixel value per channel (device). */
+int td_qwen2_patchify_u8(const void* img_hwc, int H, int W, const float* lut, int patch, int merge, int temporal, void* out, int Kpad, void* stream);
 /* out[r, :K] = bf16(src[r, :K]); out[r, K:Kpad] = 0. */
 int td_cast_pad_rows_bf16(const void* src, int src_f32, int rows, int K, void* out, int Kpad, void* stream);
 

@@ -242,3 +242,41 @@ def test_blip2_vision_on_disk_bias_names(hip, tmp_path):
     c = HipBlip2VisionModel.from_pretrained(str(tmp_path))(pix)[0]
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_qwen2_preprocessing_on_device_equals_the_image_processor(hip):
+    """QwenChatFrontend._preprocess_on_device (host: RGB conversion + smart_resize / PIL resize; device: td_qwen2_patchify_u8 with
+    the processor's own rescale / normalize table) against transformers' Qwen2VLImageProcessor on the same PIL images: grids
+    equal, patch rows bit-equal after the bf16 cast the tower applies, zero padding columns; modes L / RGBA, up- and down-sizing."""
+    import numpy as np
+    from PIL import Image
+    from transformers import Qwen2VLImageProcessor
+    from thinkdiff.models.qwen2_vl import QwenChatFrontend
+    from thinkdiff.models.vision_towers import HipQwen2VisionTransformer
+
+    class Front(QwenChatFrontend):
+        pass
+    f = Front()
+    f.visual = HipQwen2VisionTransformer.from_random(embed_dim=320, depth=1, num_heads=4, mlp_ratio=2, out_hidden=256, seed=1)
+    f.image_processor = Qwen2VLImageProcessor(min_pixels=56 * 56, max_pixels=28 * 28 * 320)
+    assert type(f.image_processor).__name__ == "Qwen2VLImageProcessorPil"      # torchvision is absent: the PIL pipeline, the one mirrored
+    rng = np.random.default_rng(0)
+    imgs = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in [(375, 500), (28, 30), (1200, 900), (224, 224)]]
+    imgs.append(Image.fromarray(rng.integers(0, 256, (90, 130), dtype=np.uint8), mode="L"))
+    imgs.append(Image.fromarray(rng.integers(0, 256, (64, 200, 4), dtype=np.uint8), mode="RGBA"))
+    got = f._preprocess_on_device(imgs)
+    assert got is not None
+    want = f.image_processor(images=imgs, return_tensors="pt")
+    assert got["image_grid_thw"] == want["image_grid_thw"].tolist()
+    K = want["pixel_values"].shape[1]
+    pv = got["pixel_values"].cpu()
+    assert pv.shape == (want["pixel_values"].shape[0], f.visual.padded_patch_dim) and pv.dtype == torch.bfloat16
+    assert torch.equal(pv[:, :K], want["pixel_values"].bfloat16()) and torch.count_nonzero(pv[:, K:]) == 0
+    # and the tower gives the same tokens either way
+    a = f.visual(got["pixel_values"], got["image_grid_thw"]).pooler_output
+    b = f.visual(want["pixel_values"], want["image_grid_thw"]).pooler_output
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # a processor of any other kind is called as is
+    f.image_processor = lambda images, return_tensors="pt": want
+    assert f._preprocess_on_device(imgs) is None

@@ -214,6 +214,10 @@ int td_rope_half_bf16(void* x, int64_t ldx, int S, int H, int head_stride, int h
 int td_vision_rope_table(const int* pos, int S, int hd, float theta, float* cos_t, float* sin_t, void* stream) {
   return td_vision_rope_table_launch(pos, S, hd, theta, cos_t, sin_t, (hipStream_t)stream);
 }
+int td_qwen2_patchify_u8(const void* img_hwc, int H, int W, const float* lut, int patch, int merge, int temporal, void* out, int Kpad, void* stream) {
+  return td_qwen2_patchify_u8_launch((const unsigned char*)img_hwc, H, W, lut, patch, merge, temporal, (bf16_t*)out, Kpad, (hipStream_t)stream);
+}
+
 int td_patchify_bf16(const void* pix, int src_f32, int C, int H, int W, int p, void* out, int Kpad, void* stream) {
   return td_patchify_launch(pix, src_f32, C, H, W, p, (bf16_t*)out, Kpad, (hipStream_t)stream);
 }

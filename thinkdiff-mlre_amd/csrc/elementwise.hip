@@ -568,6 +568,38 @@ int td_patchify_launch(const void* pix, int src_f32, int C, int H, int W, int p,
   return 0;
 }
 
+// Qwen2-VL image preprocessing after the resize, on the device ([ext] transformers Qwen2VLImageProcessor: rescale, normalize,
+// patchify): img uint8 [H, W, 3] -> out bf16 [(H/p)(W/p), Kpad], row = ((bh * (gw/m) + bw) * m + mh) * m + mw for the patch at
+// (m bh + mh, m bw + mw) (merge-window order), column = ((c * T + t) * p + py) * p + px (the still image repeated over the T
+// temporal slots), value = lut[c][pixel] -- the 3 x 256 table holds the processor's own fp32 rescale / normalize results, so the
+// arithmetic is the processor's by construction; columns [3 T p p, Kpad) zero.
+__global__ void td_qwen2_patchify_u8_kernel(const unsigned char* img, int H, int W, const float* lut, int p, int m, int T, bf16_t* out, int Kpad) {
+  __shared__ float s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += blockDim.x) s_lut[i] = lut[i];
+  __syncthreads();
+  const int gw = W / p, gw2 = gw / m;
+  const int row = blockIdx.x;
+  const int mw = row % m, mh = (row / m) % m, blk = row / (m * m);
+  const int y = (blk / gw2) * m + mh, x = (blk % gw2) * m + mw;
+  const int pp = p * p, K = 3 * T * pp;
+  for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (T * pp), r = k % pp, py = r / p, px = r % p;
+      v = s_lut[c * 256 + img[((size_t)(y * p + py) * W + (size_t)x * p + px) * 3 + c]];
+    }
+    out[(size_t)row * Kpad + k] = f2bf(v);
+  }
+}
+
+int td_qwen2_patchify_u8_launch(const unsigned char* img, int H, int W, const float* lut, int p, int m, int T, bf16_t* out, int Kpad, hipStream_t stream) {
+  TD_CHECK_ARG(img && lut && out && p > 0 && m > 0 && T > 0 && H > 0 && W > 0 && H % (p * m) == 0 && W % (p * m) == 0 && Kpad >= 3 * T * p * p,
+               "td_qwen2_patchify_u8: image %dx%d is not a multiple of patch x merge = %d, or Kpad too small", H, W, p * m);
+  hipLaunchKernelGGL(td_qwen2_patchify_u8_kernel, dim3((H / p) * (W / p)), dim3(256), 0, stream, img, H, W, lut, p, m, T, out, Kpad);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
 // out[r, 0:K] = bf16(src[r, 0:K]), out[r, K:Kpad] = 0   (pre-flattened patches -> GEMM operand)
 __global__ void td_cast_pad_rows_kernel(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

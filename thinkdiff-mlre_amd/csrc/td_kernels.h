@@ -132,6 +132,7 @@ int td_glu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, int act, h
 int td_rope_half_launch(bf16_t* x, int ldx, int S, int H, int head_stride, int hd, const float* cs, const float* sn, hipStream_t stream);
 int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, float* cs, float* sn, hipStream_t stream);
 int td_patchify_launch(const void* pix, int src_f32, int C, int H, int W, int p, bf16_t* out, int Kpad, hipStream_t stream);
+int td_qwen2_patchify_u8_launch(const unsigned char* img, int H, int W, const float* lut, int p, int m, int T, bf16_t* out, int Kpad, hipStream_t stream);
 int td_cast_pad_rows_launch(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad, hipStream_t stream);
 
 // temperature / top-p sampling over bf16 logits rows (sampler.hip): one workgroup per row, token ids to out_ids[rows]

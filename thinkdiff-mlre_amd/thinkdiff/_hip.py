@@ -78,6 +78,7 @@ def _declare(L):
         "td_rope_half_bf16": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
         "td_vision_rope_table": [vp, i32, i32, f32, vp, vp, vp],
         "td_patchify_bf16": [vp, i32, i32, i32, i32, i32, vp, i32, vp],
+        "td_qwen2_patchify_u8": [vp, i32, i32, vp, i32, i32, i32, vp, i32, vp],
         "td_cast_pad_rows_bf16": [vp, i32, i32, i32, vp, i32, vp],
         "td_vae_create": [vp, i32, i32, vp],
         "td_vae_num_params": [vp],
@@ -380,6 +381,19 @@ def rope_half(x, H, hd, cos, sin, head_stride=128):
     assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (x.shape[0], hd // 2)
     check(lib().td_rope_half_bf16(ptr(x), _rows(x), x.shape[0], H, head_stride, hd, ptr(cos), ptr(sin), stream_ptr()))
     return x
+
+
+def qwen2_patchify_u8(img, lut, patch, merge, temporal, Kpad, out=None):
+    """img uint8 [H,W,3] (cuda), lut fp32 [3,256] (cuda) -> bf16 [(H/patch)(W/patch), Kpad]: the Qwen2-VL processor's rescale,
+    normalize and patchify (merge-window row order) in one launch."""
+    H, W, C = img.shape
+    assert C == 3 and img.dtype == torch.uint8 and img.is_contiguous() and lut.dtype == torch.float32 and lut.shape == (3, 256) and lut.is_contiguous()
+    S = (H // patch) * (W // patch)
+    if out is None:
+        out = torch.empty(S, Kpad, dtype=torch.bfloat16, device=img.device)
+    assert out.shape == (S, Kpad) and out.is_contiguous() and out.dtype == torch.bfloat16
+    check(lib().td_qwen2_patchify_u8(ptr(img), H, W, ptr(lut), int(patch), int(merge), int(temporal), ptr(out), int(Kpad), stream_ptr()))
+    return out
 
 
 def patchify(pix, p, Kpad):

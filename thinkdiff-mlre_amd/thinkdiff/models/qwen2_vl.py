@@ -425,8 +425,8 @@ class QwenChatFrontend:
             raise _hip.ThinkDiffHipError("image request: load the vision tower (visual=HipQwen2VisionTransformer...) and an "
                                          "image_processor, or supply 'inputs_embeds' and 'position_ids' with the request")
         images = list(images) if isinstance(images, (list, tuple)) else [images]
-        feats = self.image_processor(images=images, return_tensors="pt")
-        grid = feats["image_grid_thw"].tolist()
+        feats = self._preprocess_on_device(images) or self.image_processor(images=images, return_tensors="pt")
+        grid = feats["image_grid_thw"].tolist() if torch.is_tensor(feats["image_grid_thw"]) else feats["image_grid_thw"]
         merged = self.visual(feats["pixel_values"], grid).pooler_output
         merge = self.visual.merge
         ids = Qwen2VLTextEngine.expand_image_placeholders(ids, grid, merge, self.image_token_id)
@@ -455,14 +455,15 @@ class QwenChatFrontend:
             im = out[i]["multi_modal_data"]["image"]
             per_req.append(list(im) if isinstance(im, (list, tuple)) else [im])
         flat = [im for ims in per_req for im in ims]
-        if len(flat) > 2:      # resize / normalise / patchify is CPU work per image: spread it over threads (PIL and numpy drop the GIL)
+        feats = self._preprocess_on_device(flat)
+        if feats is None and len(flat) > 2:      # resize / normalise / patchify is CPU work per image: spread it over threads (PIL and numpy drop the GIL)
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=min(8, len(flat))) as pool:
                 parts = list(pool.map(lambda im: self.image_processor(images=[im], return_tensors="pt"), flat))
             feats = {"pixel_values": torch.cat([f["pixel_values"] for f in parts]), "image_grid_thw": torch.cat([f["image_grid_thw"] for f in parts])}
-        else:
+        elif feats is None:
             feats = self.image_processor(images=flat, return_tensors="pt")
-        grid = feats["image_grid_thw"].tolist()
+        grid = feats["image_grid_thw"].tolist() if torch.is_tensor(feats["image_grid_thw"]) else feats["image_grid_thw"]
         merged = self.visual(feats["pixel_values"], grid).pooler_output
         merge = self.visual.merge
         counts = [t * h * w // (merge * merge) for t, h, w in grid]
@@ -480,6 +481,72 @@ class QwenChatFrontend:
             g0 += len(ims)
             m0 += n_tok
         return out
+
+    def _device_preprocess_plan(self):
+        """Settings of the image processor when its pipeline is the PIL one of transformers (convert to RGB, smart_resize +
+        PIL resize, rescale, normalize, patchify) -- then only the resize stays on the host and the rest runs as one HIP launch per
+        image (td_qwen2_patchify_u8).  None for any other processor: it is called as is."""
+        ip = self.image_processor
+        plan = getattr(self, "_dev_pre_plan", None)
+        if plan is not None and plan[0] is ip:
+            return plan[1]
+        out = None
+        try:
+            if type(ip).__name__ == "Qwen2VLImageProcessorPil" and hasattr(self.visual, "padded_patch_dim"):
+                import numpy as np
+                ramp = np.arange(256, dtype=np.uint8)[None, None, :].repeat(3, 0)          # [C, 1, 256] channels first, as the backend holds images
+                x = ip.rescale(ramp, ip.rescale_factor) if ip.do_rescale else ramp
+                x = ip.normalize(x, ip.image_mean, ip.image_std) if ip.do_normalize else x
+                lut = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(3, 256))).to(self.visual.device)
+                size = ip.size
+                out = dict(lut=lut, patch=int(ip.patch_size), merge=int(ip.merge_size), temporal=int(ip.temporal_patch_size), resample=int(ip.resample),
+                           do_resize=bool(ip.do_resize), convert_rgb=bool(ip.do_convert_rgb), min_pixels=int(size["shortest_edge"]), max_pixels=int(size["longest_edge"]))
+                if 3 * out["temporal"] * out["patch"] ** 2 > self.visual.padded_patch_dim or out["merge"] != self.visual.merge:
+                    out = None
+        except Exception:
+            out = None
+        self._dev_pre_plan = (ip, out)
+        return out
+
+    def _preprocess_on_device(self, images):
+        """PIL images -> {"pixel_values": bf16 [S, Kpad] on the device, "image_grid_thw": [[1, gh, gw], ...]} or None (caller falls back
+        to the processor).  Host: RGB conversion + the processor's smart_resize / PIL resize (threads); device: the rest."""
+        plan = self._device_preprocess_plan()
+        from PIL import Image
+        if plan is None or not images or not all(isinstance(im, Image.Image) for im in images):
+            return None
+        if not plan["convert_rgb"] and any(im.mode != "RGB" for im in images):
+            return None
+        import numpy as np
+        f = plan["patch"] * plan["merge"]
+
+        def prep(im):
+            im = im.convert("RGB") if im.mode != "RGB" else im
+            w, h = im.size
+            if plan["do_resize"]:
+                h2, w2 = smart_resize(h, w, factor=f, min_pixels=plan["min_pixels"], max_pixels=plan["max_pixels"])
+                im = im.resize((w2, h2), resample=plan["resample"])
+            elif h % f or w % f:
+                raise ValueError(f"image {w}x{h} is not a multiple of {f} and the processor does not resize")
+            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+
+        if len(images) > 2:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(16, len(images))) as pool:
+                arrs = list(pool.map(prep, images))
+        else:
+            arrs = [prep(im) for im in images]
+        p = plan["patch"]
+        grid = [[1, a.shape[0] // p, a.shape[1] // p] for a in arrs]
+        Kpad = self.visual.padded_patch_dim
+        dev = self.visual.device
+        out = torch.empty(sum(g[1] * g[2] for g in grid), Kpad, dtype=torch.bfloat16, device=dev)
+        r0 = 0
+        for a, g in zip(arrs, grid):
+            n = g[1] * g[2]
+            _hip.qwen2_patchify_u8(torch.from_numpy(a).to(dev), plan["lut"], p, plan["merge"], plan["temporal"], Kpad, out=out[r0:r0 + n])
+            r0 += n
+        return {"pixel_values": out, "image_grid_thw": grid}
 
     def resolve_request(self, r: dict) -> dict:
         """Fill prompt_token_ids (tokenizer) and, for image requests, inputs_embeds + position_ids."""

@@ -151,6 +151,11 @@ class HipQwen2VisionTransformer(_Base):
         self.m0_w, self.m0_b = g("merger.mlp.0.weight"), g("merger.mlp.0.bias")
         self.m2_w, self.m2_b = g("merger.mlp.2.weight"), g("merger.mlp.2.bias")
 
+    @property
+    def padded_patch_dim(self) -> int:
+        """Columns of the patch-embedding GEMM operand (C T p p rounded up to the k-tile)."""
+        return self.patch_w.shape[1]
+
     @classmethod
     def from_random(cls, embed_dim=1280, depth=32, num_heads=16, mlp_ratio=4, out_hidden=3584, patch_size=14, temporal_patch_size=2,
                     merge=2, seed=0, device="cuda"):
@@ -183,8 +188,13 @@ class HipQwen2VisionTransformer(_Base):
         src = hidden_states.to(self.device)
         src = src.contiguous() if src.dtype in (torch.float32, torch.bfloat16) else src.float().contiguous()
         S = src.shape[0]
-        assert src.shape[1] == self.K_in and S == sum(t * h * w for t, h, w in grid)
-        h = _hip.linear(_hip.cast_pad_rows(src, self.patch_w.shape[1]), self.patch_w)
+        assert S == sum(t * h * w for t, h, w in grid)
+        if src.dtype == torch.bfloat16 and src.shape[1] == self.patch_w.shape[1] != self.K_in:
+            padded = src               # already the GEMM operand (td_qwen2_patchify_u8: device-side preprocessing)
+        else:
+            assert src.shape[1] == self.K_in
+            padded = _hip.cast_pad_rows(src, self.patch_w.shape[1])
+        h = _hip.linear(padded, self.patch_w)
         cos, sin = _hip.vision_rope_table(vision_position_ids(grid, self.merge).to(self.device, torch.int32).contiguous(), self.hd, self.theta)
         seg, a0 = [], 0
         for t, gh, gw in grid:                     # full attention inside each frame (cu_seqlens of the reference tower)
