@@ -147,7 +147,7 @@ def test_linear_tile_288x192(hip, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(1, 3584, 18944), (1, 4608, 3584), (2, 152064, 256), (3, 1024, 3072), (5, 40, 1408), (8, 3072, 768), (1, 8, 64),
                                    (16, 3584, 18944), (13, 4608, 3584), (9, 37888, 1536), (6, 48, 64), (16, 151936, 1536),
                                    (17, 4608, 3584), (32, 1536, 8960), (33, 3584, 18944), (48, 151936, 1536), (64, 17920, 1536), (40, 48, 64),
-                                   (50, 32784, 128), (64, 1536, 1536)])
+                                   (50, 32784, 128), (64, 1536, 1536), (5, 16, 4096), (64, 2048, 1536), (16, 1536, 8960)])
 @pytest.mark.parametrize("mode", ["bias", "act", "gate_res", "none"])
 def test_skinny_m_weight_stream_kernel(hip, M, N, K, mode):
     """M <= 64 routes to csrc/gemv_bf16.hip (dot-product stream up to 4 rows, matrix-core stream with 1-4 activation blocks
@@ -163,6 +163,27 @@ def test_skinny_m_weight_stream_kernel(hip, M, N, K, mode):
                    gate=None if gate is None else gate.cuda(), res=None if res is None else res.cuda())
     torch.cuda.synchronize()
     _close(y, _ref_linear(x, w, b, act=act, gate=gate, res=res))
+
+
+def test_skinny_m_split_k_repeats_bit_for_bit(hip):
+    """Few weight blocks: K is split over workgroups and the last arriver adds the partial tiles in index order, so repeated and
+    concurrent launches (each stream has its own hand-off workspace) give the same bits; the counters re-arm themselves."""
+    M, N, K = 64, 1536, 8960
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    res = torch.randn(M, N, generator=g).bfloat16().cuda()
+    first = hip.linear(x, w, None, res=res)
+    torch.cuda.synchronize()
+    _close(first, _ref_linear(x.cpu(), w.cpu(), res=res.cpu()))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = []
+    for rep in range(8):
+        for st in streams:
+            with torch.cuda.stream(st):
+                outs.append(hip.linear(x, w, None, res=res))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, first) for o in outs)
 
 
 def test_skinny_m_split_output_and_strided_rows(hip):

@@ -8,6 +8,10 @@
 //   * bf16 pairs go straight into v_dot2c_f32_bf16 (fp32 accumulate, no unpacking);
 //   * wave shuffle + LDS cross-wave reduction, then the same epilogue semantics and bf16 rounding points as the tile kernel
 //     (bias, activation, gate, residual, split output).
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
 #include "td_common.h"
 #include "td_kernels.h"
 
@@ -136,47 +140,68 @@ __global__ __launch_bounds__(THREADS) void td_gemv_bf16_kernel(const TdGemmParam
 // Accumulators are reduced across waves through LDS, one weight block at a time.
 constexpr int MW = 8;   // waves per workgroup (K split)
 
-template <int MB, int NR>
-__global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParams p) {
+// Few weight blocks (N = hidden: 96 blocks for the 2B decoder, 224 for the 7B one) leave most CUs without a workgroup.  Then K is
+// also split across KS workgroups per block column (gridDim.y): each leaves its fp32 partial tiles in a workspace and draws a
+// ticket; the LAST to arrive adds the KS partials in index order (the result does not depend on who finishes) and runs the epilogue.
+// Hand-off as in the stream-K attention kernel: write-through (sc1) 16-byte stores, every storing wave drains, workgroup barrier,
+// one agent-scope atomic; reader: one agent-scope acquire, barrier, plain loads.  The finisher re-arms the counter.
+constexpr int SPLITK_MAX_WGS = 512;                       // block columns a split launch may have (sizes the counter array)
+constexpr size_t SPLITK_HEADER_BYTES = SPLITK_MAX_WGS * 4;
+constexpr size_t SPLITK_PART_BYTES = (size_t)SPLITK_MAX_WGS * 4 * 8 * 1024;   // block columns x MB x KS x (64 lanes x 16 B)
+
+template <int MB, int NR, bool DEEP>
+__global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParams p, char* ws) {
   __shared__ float red[MW][MB][64][4];
+  __shared__ unsigned ticket_lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;         // 16-row weight blocks of the problem
-  const bf16_t* wrow[NR];
+  const int KS = gridDim.y, ky = blockIdx.y;
+  // Operands through buffer descriptors: a k-step past this workgroup's range is sent beyond the descriptor and reads zeros, so
+  // the loop body is branch-free.  DEEP (long K: at least 4 steps per wave): all loads of SF steps -- up to 32 per lane -- are in
+  // flight before the first MFMA (a workgroup streams only 16 rows x K, its lifetime is a handful of memory round trips);
+  // otherwise hipcc threads the loads between the MFMAs at ~64 VGPRs, which keeps four workgroups per CU for short K.
+  const unsigned w_rows = p.glu_I ? 2u * (unsigned)p.glu_I : (unsigned)p.N;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)w_rows * p.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((((size_t)p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned woff[NR], xoff[MB];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int bid = min((int)blockIdx.x * NR + nr, nblk - 1);
     // gated mode: rows 0-7 = gate rows 8b..8b+7, rows 8-15 = the matching up rows
     const int wr_ = p.glu_I ? (bid * 8 + (r & 7) + (r >> 3) * p.glu_I) : bid * 16 + r;
-    wrow[nr] = p.W + (size_t)wr_ * p.K + 8 * g;
+    woff[nr] = (unsigned)(((size_t)wr_ * p.K + 8 * g) * 2);
   }
-  const bf16_t* xrow[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) xrow[mb] = p.A + (size_t)min(16 * mb + r, p.M - 1) * p.lda + 8 * g;
-  const int nk = p.K >> 6;                      // 64-element steps
+  for (int mb = 0; mb < MB; ++mb) xoff[mb] = (unsigned)(((size_t)min(16 * mb + r, p.M - 1) * p.lda + 8 * g) * 2);
+  const int nk_all = p.K >> 6;                  // 64-element steps
+  const int s_beg = (int)((long long)nk_all * ky / KS), nk = (int)((long long)nk_all * (ky + 1) / KS);   // this workgroup's steps
   f32x4_t acc[NR][MB];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[nr][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  constexpr int SF = (MB * NR == 1) ? 2 : 1;    // k-steps in flight per wave: 4 (SF = 2) or 2 NR + 2 MB 16-byte loads per lane
-  int s = wid;
-  for (; s + (SF - 1) * MW < nk; s += SF * MW) {
+  constexpr int SF = DEEP ? 32 / (2 * NR + 2 * MB) : (MB * NR == 1 ? 2 : 1);    // k-steps per wave and iteration
+  for (int s = s_beg + wid; s < nk; s += SF * MW) {
     bf16x8_t w[SF][NR][2], x[SF][MB][2];
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
-      const size_t k0 = (size_t)(s + f * MW) * 64;
+      const int st = s + f * MW;
+      const bool ok = st < nk;
+      const unsigned k0 = (unsigned)st * 128u;
 #pragma unroll
-      for (int nr = 0; nr < NR; ++nr) {
-        w[f][nr][0] = __builtin_nontemporal_load((const bf16x8_t*)(wrow[nr] + k0));
-        w[f][nr][1] = __builtin_nontemporal_load((const bf16x8_t*)(wrow[nr] + k0 + 32));
-      }
+      for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        x[f][mb][0] = *(const bf16x8_t*)(xrow[mb] + k0);
-        x[f][mb][1] = *(const bf16x8_t*)(xrow[mb] + k0 + 32);
-      }
+        for (int h = 0; h < 2; ++h)
+          w[f][nr][h] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, ok ? woff[nr] + k0 + 64u * h : OOB, 0, 0));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          x[f][mb][h] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? xoff[mb] + k0 + 64u * h : OOB, 0, 0));
     }
+    if (DEEP) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise threads the loads between the MFMAs and keeps 4-6 of them in flight
 #pragma unroll
     for (int f = 0; f < SF; ++f)
 #pragma unroll
@@ -186,31 +211,9 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) acc[nr][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][nr][h], x[f][mb][h], acc[nr][mb], 0, 0, 0);
   }
-  if (SF == 2 && s < nk) {
-    const size_t k0 = (size_t)s * 64;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bf16x8_t w0 = __builtin_nontemporal_load((const bf16x8_t*)(wrow[0] + k0 + 32 * h));
-      const bf16x8_t x0 = *(const bf16x8_t*)(xrow[0] + k0 + 32 * h);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[0][0], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr) {
-    if (nr) __syncthreads();
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) red[wid][mb][lane][i] = acc[nr][mb][i];
-    __syncthreads();
-    const int bid = blockIdx.x * NR + nr;
-    if (wid >= MB || bid >= nblk) continue;       // wave mb finishes activation block mb of this weight block
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < MW; ++w)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += red[w][wid][lane][i];
-    // C layout of the MFMA: column (lane & 15) = activation row, rows 4 (lane >> 4) + i = weight rows
+
+  // wave mb (< MB) finishes activation block mb: v = fp32 tile column (lane & 15) = activation row, rows 4 (lane >> 4) + i = weight rows
+  auto epilogue = [&](int bid, float (&v)[4]) {
     const int m = 16 * wid + r;
     if (p.glu_I) {   // lanes g = 0,1 hold gate rows 4g+i, their partners 32 lanes up the matching up rows
       float u[4];
@@ -221,10 +224,10 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
         for (int i = 0; i < 4; ++i) v[i] = rbf(silu_f(rbf(v[i]))) * rbf(u[i]);
         *(u32x2_t*)(p.C + (size_t)m * p.ldc + bid * 8 + 4 * g) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
       }
-      continue;
+      return;
     }
     const int n = bid * 16 + 4 * g;
-    if (m >= p.M) continue;
+    if (m >= p.M) return;
     const bool second = p.C2 != nullptr && n >= p.n_split;
     const int act = second ? p.act2 : p.act;
 #pragma unroll
@@ -241,28 +244,110 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
     const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     if (second) *(u32x2_t*)(p.C2 + (size_t)m * p.ldc2 + (n - p.n_split)) = o;
     else *(u32x2_t*)(p.C + (size_t)m * p.ldc + n) = o;
+  };
+  // partial tile of (block column, nr, mb, k-part): 64 lanes x 16 bytes
+  const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + SPLITK_HEADER_BYTES), 0, (unsigned)SPLITK_PART_BYTES, 0x00020000);
+  auto part = [&](int nr, int mb, int part_k) -> unsigned {
+    return (unsigned)((((blockIdx.x * NR + nr) * MB + mb) * KS + part_k) * 64 + lane) * 16u;
+  };
+
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    if (nr) __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wid][mb][lane][i] = acc[nr][mb][i];
+    __syncthreads();
+    const int bid = blockIdx.x * NR + nr;
+    if (wid >= MB || bid >= nblk) continue;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < MW; ++w)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += red[w][wid][lane][i];
+    if (KS == 1) epilogue(bid, v);
+    else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{as_u32(v[0]), as_u32(v[1]), as_u32(v[2]), as_u32(v[3])}, rsP, part(nr, wid, ky), 0, 16);   // aux 16 = sc1
+  }
+  if (KS == 1) return;
+  // ---- split K: publish, draw the ticket, the last arriver sums the parts in index order and finishes ------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned* cnt = (unsigned*)ws + blockIdx.x;
+  if (tid == 0) ticket_lds = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_lds != (unsigned)(KS - 1)) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket drawn: ready for the next launch
+  if (wid >= MB) return;
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int bid = blockIdx.x * NR + nr;
+    if (bid >= nblk) continue;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KS; ++k) {
+      const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rsP, part(nr, wid, k), 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += as_f32(t[i]);
+    }
+    epilogue(bid, v);
   }
 }
 
-template <int MB>
-void launch_mfma(const TdGemmParams& p, hipStream_t stream) {
-  const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;
-  // two weight blocks per workgroup halve the x re-reads from L2; only where the grid still oversubscribes the chip
-  if (MB > 1 && nblk >= 2048) hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 2>), dim3((nblk + 1) / 2), dim3(MW * 64), 0, stream, p);
-  else hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 1>), dim3(nblk), dim3(MW * 64), 0, stream, p);
+// one hand-off workspace per (device, stream): launches on one stream never overlap
+int splitk_workspace(hipStream_t stream, char** out) {
+  struct Entry { int dev; hipStream_t stream; char* ws; };
+  static std::mutex mu;
+  static std::vector<Entry> pool;
+  int dev = 0;
+  TD_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& e : pool)
+    if (e.dev == dev && e.stream == stream) { *out = e.ws; return 0; }
+  char* w = nullptr;
+  TD_CHECK_HIP(hipMalloc((void**)&w, SPLITK_HEADER_BYTES + SPLITK_PART_BYTES));
+  TD_CHECK_HIP(hipMemsetAsync(w, 0, SPLITK_HEADER_BYTES, stream));      // on the launching stream (ordered before the kernel)
+  pool.push_back(Entry{dev, stream, w});
+  *out = w;
+  return 0;
 }
 
-void launch_mfma_rows(const TdGemmParams& p, hipStream_t stream) {
-  if (p.M <= 16) launch_mfma<1>(p, stream);
-  else if (p.M <= 32) launch_mfma<2>(p, stream);
-  else if (p.M <= 48) launch_mfma<3>(p, stream);
-  else launch_mfma<4>(p, stream);
+template <int MB>
+int launch_mfma(const TdGemmParams& p, hipStream_t stream) {
+  const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;
+  // two weight blocks per workgroup halve the x re-reads from L2; only where the grid still oversubscribes the chip
+  if (MB > 1 && nblk >= 1024) {
+    if ((p.K >> 6) >= 4 * MW) hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 2, true>), dim3((nblk + 1) / 2), dim3(MW * 64), 0, stream, p, (char*)nullptr);
+    else hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 2, false>), dim3((nblk + 1) / 2), dim3(MW * 64), 0, stream, p, (char*)nullptr);
+    return 0;
+  }
+  // few block columns: split K over workgroups too, as long as every wave of a workgroup keeps at least one 64-element step
+  int ks = 1;
+  if (nblk < SPLITK_MAX_WGS / 2) ks = std::max(1, std::min({8, SPLITK_MAX_WGS / nblk, (p.K >> 6) / MW}));
+  char* ws = nullptr;
+  if (ks > 1) {
+    if (int rc = splitk_workspace(stream, &ws)) return rc;
+  }
+  if ((p.K >> 6) / ks >= 4 * MW) hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 1, true>), dim3(nblk, ks), dim3(MW * 64), 0, stream, p, ws);
+  else hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 1, false>), dim3(nblk, ks), dim3(MW * 64), 0, stream, p, ws);
+  return 0;
+}
+
+int launch_mfma_rows(const TdGemmParams& p, hipStream_t stream) {
+  if (p.M <= 16) return launch_mfma<1>(p, stream);
+  if (p.M <= 32) return launch_mfma<2>(p, stream);
+  if (p.M <= 48) return launch_mfma<3>(p, stream);
+  return launch_mfma<4>(p, stream);
 }
 
 }  // namespace
 
 // shapes the matrix-core weight stream takes (td_gemm_launch asks before routing 16 < M <= 64 here)
 bool td_gemv_mfma_ok(const TdGemmParams& p) {
+  const long long w_rows = p.glu_I ? 2ll * p.glu_I : p.N;          // operands sit behind 32-bit buffer descriptors
+  if (w_rows * p.K * 2 >= 0xFFFFFF00ll || ((long long)(p.M - 1) * p.lda + p.K) * 2 >= 0xFFFFFF00ll) return false;
   return p.K % 64 == 0 && p.N % 16 == 0 && p.ldc % 4 == 0 && p.lda % 8 == 0 && (!p.C2 || (p.ldc2 % 4 == 0 && p.n_split % 4 == 0));
 }
 
@@ -273,9 +358,11 @@ int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
   if (p.glu_I) {
     TD_CHECK_ARG(p.N == p.glu_I && p.glu_I % 8 == 0 && !p.bias && !p.gate && !p.res && !p.C2 && p.act == TD_ACT_NONE && p.ldc % 4 == 0,
                  "td_gemv(glu): N must equal glu_I (multiple of 8), no bias / gate / residual / split");
-    TD_CHECK_ARG(p.M <= 16 || p.K % 64 == 0, "td_gemv(glu): more than 16 rows need K %% 64 == 0");
-    if (p.M > 4 && p.K % 64 == 0) launch_mfma_rows(p, stream);
-    else if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
+    const bool mfma = p.K % 64 == 0 && 2ll * p.glu_I * p.K * 2 < 0xFFFFFF00ll && ((long long)(p.M - 1) * p.lda + p.K) * 2 < 0xFFFFFF00ll;
+    TD_CHECK_ARG(p.M <= 16 || mfma, "td_gemv(glu): more than 16 rows need K %% 64 == 0 and operands under 4 GiB");
+    if (p.M > 4 && mfma) {
+      if (int rc = launch_mfma_rows(p, stream)) return rc;
+    } else if (p.M == 1) hipLaunchKernelGGL(td_gemv_bf16_kernel<1>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
     else if (p.M == 2) hipLaunchKernelGGL(td_gemv_bf16_kernel<2>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
     else if (p.M <= 4) hipLaunchKernelGGL(td_gemv_bf16_kernel<4>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
     else if (p.M <= 8) hipLaunchKernelGGL(td_gemv_bf16_kernel<8>, dim3(p.glu_I / 2), dim3(THREADS), 0, stream, p);
@@ -284,7 +371,7 @@ int td_gemv_launch(const TdGemmParams& p, hipStream_t stream) {
     return 0;
   }
   if (p.M > 4 && td_gemv_mfma_ok(p)) {
-    launch_mfma_rows(p, stream);
+    if (int rc = launch_mfma_rows(p, stream)) return rc;
     TD_CHECK_LAUNCH();
     return 0;
   }

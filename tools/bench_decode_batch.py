@@ -8,14 +8,15 @@ from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
 shapes = {"2B": Qwen2VLTextConfig(hidden_size=1536, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2, intermediate_size=8960,
                                   vocab_size=151936, tie_word_embeddings=True),
           "7B": Qwen2VLTextConfig()}
-which = sys.argv[1:] or ["2B", "7B"]
+which = [a for a in sys.argv[1:] if not a.isdigit()] or ["2B", "7B"]
+batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 4, 8, 16, 24, 32, 48, 64]
 CACHE = 300
 for name in which:
     cfg = shapes[name]
     e = Qwen2VLTextEngine(cfg, max_model_len=512, n_slots=64, prefill_rows=64 * 320).init_random(0)
     wbytes = 2 * (cfg.num_hidden_layers * (cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * 128 + cfg.num_attention_heads * 128 * cfg.hidden_size
                   + 3 * cfg.hidden_size * cfg.intermediate_size) + cfg.vocab_size * cfg.hidden_size)
-    for B in (1, 4, 8, 16, 24, 32, 48, 64):
+    for B in batches:
         toks = [5] * B
         for rep in range(2):
             torch.cuda.synchronize()
