@@ -9,6 +9,7 @@
 //   * wave shuffle + LDS cross-wave reduction, then the same epilogue semantics and bf16 rounding points as the tile kernel
 //     (bias, activation, gate, residual, split output).
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -149,32 +150,59 @@ constexpr int SPLITK_MAX_WGS = 512;                       // block columns a spl
 constexpr size_t SPLITK_HEADER_BYTES = SPLITK_MAX_WGS * 4;
 constexpr size_t SPLITK_PART_BYTES = (size_t)SPLITK_MAX_WGS * 4 * 8 * 1024;   // block columns x MB x KS x (64 lanes x 16 B)
 
+// LDS bytes of one workgroup: per wave a private slab of 2 NR weight + 2 XB activation 1-KiB fragments (one k-step; more than two
+// activation blocks take turns in the slab, which keeps 2-3 workgroups per CU at 64 sequences), reused for the cross-wave
+// reduction (MB KiB per wave) after the loop
+template <int MB> constexpr int gemv_xb() { return MB > 2 ? 2 : MB; }     // activation blocks passing through the slab together
+template <int MB, int NR> constexpr int gemv_lds_bytes() { return MW * (2 * NR + 2 * gemv_xb<MB>()) * 1024; }
+
 template <int MB, int NR, bool DEEP>
 __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParams p, char* ws) {
-  __shared__ float red[MW][MB][64][4];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XB = gemv_xb<MB>();
+  constexpr int SLAB = (2 * NR + 2 * XB) * 1024;
+  float (*red)[SLAB / 4] = (float (*)[SLAB / 4])smem;        // red[wave][(mb * 64 + lane) * 4 + i], MB KiB of each wave's slab
   __shared__ unsigned ticket_lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;         // 16-row weight blocks of the problem
   const int KS = gridDim.y, ky = blockIdx.y;
   // Operands through buffer descriptors: a k-step past this workgroup's range is sent beyond the descriptor and reads zeros, so
-  // the loop body is branch-free.  DEEP (long K: at least 4 steps per wave): all loads of SF steps -- up to 32 per lane -- are in
-  // flight before the first MFMA (a workgroup streams only 16 rows x K, its lifetime is a handful of memory round trips);
-  // otherwise hipcc threads the loads between the MFMAs at ~64 VGPRs, which keeps four workgroups per CU for short K.
+  // the loop body is branch-free.  A load instruction covers 8 rows x one whole 128-byte line each (lane = row l / 8, 16-byte chunk
+  // l % 8): in MFMA operand layout (4 lanes per row) it would touch 16 half lines, and the other halves, fetched by the next
+  // instruction, no longer find their lines in the 16 KiB L1 -- measured with a timing-only build: -17 % (16 sequences) to -27 %
+  // (64) per decode step.  The fragments then pass through a wave-private LDS slab into operand layout: ds_write_b128 at lane x 16
+  // (conflict-free), ds_read_b128 of row r, chunk 4 h + g; the chunk a lane FETCHES is XOR-ed with its row so those reads spread
+  // over the banks.  LDS operations of a wave execute in order, so the slab needs no barrier between steps.
+  // DEEP (long K: at least 4 steps per wave): all loads of SF steps -- up to 32 per lane -- are in flight before the first
+  // LDS pass (a workgroup streams only 16 rows x K, its lifetime is a handful of memory round trips); otherwise hipcc threads
+  // the loads between the steps at low register count, which keeps several workgroups per CU for short K.
   const unsigned w_rows = p.glu_I ? 2u * (unsigned)p.glu_I : (unsigned)p.N;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)w_rows * p.K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((((size_t)p.M - 1) * p.lda + p.K) * 2), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
-  unsigned woff[NR], xoff[MB];
+  const int lrow = lane >> 3;                                  // row of the 8-row half this lane fetches
+  const int lchunk = (lane & 7) ^ (lrow & 7);                  // ... and which 16-byte chunk of the row's 128-byte line
+  unsigned woff[NR][2], xoff[MB][2];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int bid = min((int)blockIdx.x * NR + nr, nblk - 1);
-    // gated mode: rows 0-7 = gate rows 8b..8b+7, rows 8-15 = the matching up rows
-    const int wr_ = p.glu_I ? (bid * 8 + (r & 7) + (r >> 3) * p.glu_I) : bid * 16 + r;
-    woff[nr] = (unsigned)(((size_t)wr_ * p.K + 8 * g) * 2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // gated mode: rows 0-7 = gate rows 8b..8b+7, rows 8-15 = the matching up rows
+      const int wr_ = p.glu_I ? (bid * 8 + lrow + h * p.glu_I) : bid * 16 + 8 * h + lrow;
+      woff[nr][h] = (unsigned)(((size_t)wr_ * p.K + 8 * lchunk) * 2);
+    }
   }
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) xoff[mb] = (unsigned)(((size_t)min(16 * mb + r, p.M - 1) * p.lda + 8 * g) * 2);
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) xoff[mb][h] = (unsigned)(((size_t)min(16 * mb + 8 * h + lrow, p.M - 1) * p.lda + 8 * lchunk) * 2);
+  char* slab = smem + wid * SLAB;
+  u32x4_t* wr_ptr = (u32x4_t*)(slab + lane * 16);                                 // + fragment * 1024
+  const char* rd_ptr[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) rd_ptr[h] = slab + r * 128 + (((4 * h + g) ^ (r & 7)) << 4);   // + block * 2048
   const int nk_all = p.K >> 6;                  // 64-element steps
   const int s_beg = (int)((long long)nk_all * ky / KS), nk = (int)((long long)nk_all * (ky + 1) / KS);   // this workgroup's steps
   f32x4_t acc[NR][MB];
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
     for (int mb = 0; mb < MB; ++mb) acc[nr][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   constexpr int SF = DEEP ? 32 / (2 * NR + 2 * MB) : (MB * NR == 1 ? 2 : 1);    // k-steps per wave and iteration
   for (int s = s_beg + wid; s < nk; s += SF * MW) {
-    bf16x8_t w[SF][NR][2], x[SF][MB][2];
+    u32x4_t w[SF][NR][2], x[SF][MB][2];
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
       const int st = s + f * MW;
@@ -193,24 +221,49 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          w[f][nr][h] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, ok ? woff[nr] + k0 + 64u * h : OOB, 0, 0));
+        for (int h = 0; h < 2; ++h) w[f][nr][h] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ok ? woff[nr][h] + k0 : OOB, 0, 0);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          x[f][mb][h] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? xoff[mb] + k0 + 64u * h : OOB, 0, 0));
+        for (int h = 0; h < 2; ++h) x[f][mb][h] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? xoff[mb][h] + k0 : OOB, 0, 0);
     }
-    if (DEEP) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise threads the loads between the MFMAs and keeps 4-6 of them in flight
+    if (DEEP) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise threads the loads between the steps and keeps 4-6 of them in flight
 #pragma unroll
-    for (int f = 0; f < SF; ++f)
+    for (int f = 0; f < SF; ++f) {
+      // block b of the slab: fragments 2b (rows 0-7) and 2b + 1 (rows 8-15); weight blocks first, then activation blocks
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr)
+        for (int h = 0; h < 2; ++h) wr_ptr[(2 * nr + h) * 64] = w[f][nr][h];
+      bf16x8_t wf[NR][2];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[nr][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][nr][h], x[f][mb][h], acc[nr][mb], 0, 0, 0);
+      for (int m0 = 0; m0 < MB; m0 += XB) {       // XB activation blocks at a time through the slab
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (m0 + j < MB) wr_ptr[(2 * (NR + j) + h) * 64] = x[f][m0 + j < MB ? m0 + j : 0][h];
+        bf16x8_t xf[XB][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (m0 == 0) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) wf[nr][h] = *(const bf16x8_t*)(rd_ptr[h] + nr * 2048);
+          }
+#pragma unroll
+          for (int j = 0; j < XB; ++j) xf[j][h] = *(const bf16x8_t*)(rd_ptr[h] + (NR + j) * 2048);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int j = 0; j < XB; ++j)
+              if (m0 + j < MB) acc[nr][m0 + j < MB ? m0 + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nr][h], xf[j][h], acc[nr][m0 + j < MB ? m0 + j : 0], 0, 0, 0);
+      }
+    }
   }
+  __syncthreads();          // every wave is done with its slab before the reduction reuses the space
 
   // wave mb (< MB) finishes activation block mb: v = fp32 tile column (lane & 15) = activation row, rows 4 (lane >> 4) + i = weight rows
   auto epilogue = [&](int bid, float (&v)[4]) {
@@ -256,16 +309,17 @@ __global__ __launch_bounds__(MW * 64) void td_gemv_mfma_kernel(const TdGemmParam
     if (nr) __syncthreads();
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) red[wid][mb][lane][i] = acc[nr][mb][i];
+      *(f32x4_t*)&red[wid][(mb * 64 + lane) * 4] = acc[nr][mb];
     __syncthreads();
     const int bid = blockIdx.x * NR + nr;
     if (wid >= MB || bid >= nblk) continue;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < MW; ++w)
+    for (int w = 0; w < MW; ++w) {
+      const f32x4_t t = *(const f32x4_t*)&red[w][(wid * 64 + lane) * 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += red[w][wid][lane][i];
+      for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
     if (KS == 1) epilogue(bid, v);
     else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{as_u32(v[0]), as_u32(v[1]), as_u32(v[2]), as_u32(v[3])}, rsP, part(nr, wid, ky), 0, 16);   // aux 16 = sc1
   }
@@ -314,14 +368,29 @@ int splitk_workspace(hipStream_t stream, char** out) {
   return 0;
 }
 
+template <int MB, int NR, bool DEEP>
+int launch_one(const TdGemmParams& p, dim3 grid, char* ws, hipStream_t stream) {
+  constexpr int lds = gemv_lds_bytes<MB, NR>();
+  if (lds > 64 * 1024) {        // beyond the default dynamic-LDS limit: raise it once per device
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    TD_CHECK_HIP(hipGetDevice(&dev));
+    if (!((done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+      TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemv_mfma_kernel<MB, NR, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, NR, DEEP>), grid, dim3(MW * 64), lds, stream, p, ws);
+  return 0;
+}
+
 template <int MB>
 int launch_mfma(const TdGemmParams& p, hipStream_t stream) {
   const int nblk = p.glu_I ? p.glu_I / 8 : p.N / 16;
   // two weight blocks per workgroup halve the x re-reads from L2; only where the grid still oversubscribes the chip
   if (MB > 1 && nblk >= 1024) {
-    if ((p.K >> 6) >= 4 * MW) hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 2, true>), dim3((nblk + 1) / 2), dim3(MW * 64), 0, stream, p, (char*)nullptr);
-    else hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 2, false>), dim3((nblk + 1) / 2), dim3(MW * 64), 0, stream, p, (char*)nullptr);
-    return 0;
+    const dim3 grid((nblk + 1) / 2);
+    return (p.K >> 6) >= 4 * MW ? launch_one<MB, 2, true>(p, grid, nullptr, stream) : launch_one<MB, 2, false>(p, grid, nullptr, stream);
   }
   // few block columns: split K over workgroups too, as long as every wave of a workgroup keeps at least one 64-element step
   int ks = 1;
@@ -330,9 +399,8 @@ int launch_mfma(const TdGemmParams& p, hipStream_t stream) {
   if (ks > 1) {
     if (int rc = splitk_workspace(stream, &ws)) return rc;
   }
-  if ((p.K >> 6) / ks >= 4 * MW) hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 1, true>), dim3(nblk, ks), dim3(MW * 64), 0, stream, p, ws);
-  else hipLaunchKernelGGL((td_gemv_mfma_kernel<MB, 1, false>), dim3(nblk, ks), dim3(MW * 64), 0, stream, p, ws);
-  return 0;
+  const dim3 grid(nblk, ks);
+  return (p.K >> 6) / ks >= 4 * MW ? launch_one<MB, 1, true>(p, grid, ws, stream) : launch_one<MB, 1, false>(p, grid, ws, stream);
 }
 
 int launch_mfma_rows(const TdGemmParams& p, hipStream_t stream) {
