@@ -323,6 +323,9 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
  * hidden_out bf16[B*L,hidden], logits_last bf16[B,vocab] of each sequence's last real token (either may be NULL). */
 int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
                            const int* lens, void* hidden_out, void* logits_last, void* stream);
+/* ... into slots slot0..slot0+B-1: a request batch with B x L above ws_rows is prefilled in several calls */
+int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                              const int* lens, void* hidden_out, void* logits_last, void* stream);
 int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache rows of an existing handle */
 int td_qwen2_slot_capacity(const td_qwen2* f);
 /* copy the first `len` cache rows of sequence src to sequence dst (compaction when a sequence finishes) */

@@ -174,6 +174,32 @@ def test_batched_decode_of_forty_sequences(hip):
         assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
 
 
+def test_batched_prefill_in_several_passes(hip):
+    """A request batch whose padded prompts exceed the activation workspace (40 x 64 rows against 256) is prefilled four
+    sequences per pass into consecutive cache slots (td_qwen2_prefill_batch_at): same states as one request at a time."""
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=13)
+    e = Qwen2VLTextEngine(Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
+                                            num_key_value_heads=cfg.num_kv_heads, intermediate_size=cfg.intermediate, vocab_size=cfg.vocab,
+                                            tie_word_embeddings=cfg.tie_embeddings), max_model_len=256, n_slots=40, prefill_rows=256)
+    e.load_state_dict(sd)
+    assert e.prefill_rows == 256 and e.slot_len == 256
+    g = torch.Generator().manual_seed(9)
+    B = 40
+    lens = [3 + (11 * i) % 58 for i in range(B)]
+    reqs = [{"prompt_token_ids": torch.randint(0, cfg.vocab, (n,), generator=g).tolist()} for n in lens]
+    forced = [torch.randint(0, cfg.vocab, (2,), generator=g).tolist() for _ in range(B)]
+    sp = SamplingParams(max_tokens=2, min_tokens=2, ignore_eos=True)
+    batch = e.generate_batch(reqs, sp, forced_output_ids=forced)
+    batch = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in batch]
+    torch.cuda.synchronize()
+    for r, f, b in zip(reqs, forced, batch):
+        a = e.generate(r["prompt_token_ids"], sp, forced_output_ids=f)
+        assert b["prompt_hidden_states"].shape == a["prompt_hidden_states"].shape
+        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 5e-3 and _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
+
+
 def test_get_embed_batches_requests(hip):
     """get_embed over several requests with max_num_seqs > 1 runs them through generate_batch: same aligner inputs as one
     request at a time (teacher-forced)."""

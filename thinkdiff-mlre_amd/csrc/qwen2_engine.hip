@@ -453,9 +453,15 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
 // (rows past lens[b] are meaningless), logits_last bf16[B, vocab] of each sequence's last real token (either may be NULL).
 int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
                            const int* lens, void* hidden_out, void* logits_last, void* stream) {
+  return td_qwen2_prefill_batch_at(f, 0, B, L, token_ids, inputs_embeds, position_ids, lens, hidden_out, logits_last, stream);
+}
+
+// ... into cache slots slot0 .. slot0 + B - 1 (a request batch larger than the activation workspace is prefilled in several calls)
+int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                              const int* lens, void* hidden_out, void* logits_last, void* stream) {
   TD_CHECK_ARG(f && position_ids && lens && (token_ids || inputs_embeds), "td_qwen2_prefill_batch: null argument");
-  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && L >= 1 && L <= f->slot_len && (long long)B * L <= f->ws_rows,
-               "td_qwen2_prefill_batch: B=%d x L=%d exceeds the handle (slots %d x %d tokens, workspace %d rows)", B, L, f->n_slots, f->slot_len, f->ws_rows);
+  TD_CHECK_ARG(slot0 >= 0 && B >= 1 && B <= MAX_BATCH && slot0 + B <= f->n_slots && L >= 1 && L <= f->slot_len && (long long)B * L <= f->ws_rows,
+               "td_qwen2_prefill_batch: slots [%d, %d) x L=%d exceed the handle (slots %d x %d tokens, workspace %d rows)", slot0, slot0 + B, L, f->n_slots, f->slot_len, f->ws_rows);
   for (int b = 0; b < B; ++b) TD_CHECK_ARG(lens[b] >= 1 && lens[b] <= L, "td_qwen2_prefill_batch: sequence %d has %d of %d tokens", b, lens[b], L);
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
@@ -490,9 +496,10 @@ int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, cons
     }
     TDQ_TRY(td_qk_norm_rope_launch(rq, s));
     TDQ_TRY(td_qk_norm_rope_launch(rk, s));
-    hipLaunchKernelGGL(td_kv_rows_to_slots_kernel, dim3((KVW / 8 + 255) / 256, n), dim3(256), 0, s, f->kvtmp, l.kv, L, f->slot_len, KVW);
+    bf16_t* kv0 = l.kv + (size_t)slot0 * f->slot_len * KVW;      // first slot of this call
+    hipLaunchKernelGGL(td_kv_rows_to_slots_kernel, dim3((KVW / 8 + 255) / 256, n), dim3(256), 0, s, f->kvtmp, kv0, L, f->slot_len, KVW);
     TdAttnParams ap;
-    ap.Q = f->q; ap.ldq = QW; ap.q_bstride = (long long)L * QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW;
+    ap.Q = f->q; ap.ldq = QW; ap.q_bstride = (long long)L * QW; ap.K = kv0; ap.V = kv0 + Hkv * 128; ap.ldkv = KVW;
     ap.kv_bstride = (long long)f->slot_len * KVW; ap.O = f->attn; ap.ldo = QW; ap.o_bstride = (long long)L * QW;
     ap.batch = B; ap.Sq = L; ap.Skv = L; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f; ap.causal = 1; ap.causal_offset = 0;
     TDQ_TRY(td_attn_launch(ap, s));

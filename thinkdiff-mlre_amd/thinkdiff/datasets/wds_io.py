@@ -32,7 +32,10 @@ def encode_value(ext: str, value: Any) -> bytes:
     if base in ("pth", "pt"):
         import torch
         buf = io.BytesIO()
-        torch.save(value, buf)
+        if hasattr(value, "save") and not torch.is_tensor(value):
+            value.save(buf)                  # deferred serialisation (a view into a batch-wide tensor, cloned on the writer thread)
+        else:
+            torch.save(value, buf)
         return buf.getvalue()
     raise ValueError(f"no encoder for extension {ext!r} and value of type {type(value)}")
 
@@ -52,6 +55,12 @@ def decode_value(ext: str, data: bytes) -> Any:
         import torch
         return torch.load(io.BytesIO(data), map_location="cpu", weights_only=True)
     return data
+
+
+def encode_sample(sample: Dict[str, Any]) -> Dict[str, Any]:
+    """Every member of a sample as bytes (what TarWriter.write would produce); `__*` entries pass through.  Lets the JPEG /
+    torch.save / json encoding run on worker threads while one thread appends to the tar in order."""
+    return {ext: (value if ext.startswith("__") else encode_value(ext, value)) for ext, value in sample.items()}
 
 
 class TarWriter:
@@ -150,7 +159,7 @@ def read_tar_samples(path: str, decode: bool = True) -> List[Dict[str, Any]]:
 class ShardListDataset:
     """Map-style view of a wids index (`wids.ShardListDataset(json, keep=True, localname=identity)`)."""
 
-    def __init__(self, index, shards: Optional[List[Dict[str, Any]]] = None, cache_shards: int = 2):
+    def __init__(self, index, shards: Optional[List[Dict[str, Any]]] = None, cache_shards: Optional[int] = None, chunksize: int = 1000):
         if shards is None:
             with open(index) as fh:
                 desc = json.load(fh)
@@ -165,6 +174,11 @@ class ShardListDataset:
         for s in shards:
             self.cum.append(self.cum[-1] + int(s["nsamples"]))
         self._cache: Dict[int, List[Dict[str, Any]]] = {}
+        if cache_shards is None:
+            # the chunked sampler shuffles inside windows of `chunksize` consecutive samples: keep every shard such a window can
+            # touch (2 for the usual multi-thousand-sample shards; small shards would otherwise be re-read on every other access)
+            smallest = max(1, min((int(s["nsamples"]) for s in shards), default=1))
+            cache_shards = min(256, 2 + (chunksize + smallest - 1) // smallest)
         self._cache_shards = cache_shards
 
     def __len__(self):

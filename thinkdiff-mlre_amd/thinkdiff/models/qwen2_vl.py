@@ -273,24 +273,29 @@ class Qwen2VLTextEngine:
         poss = [self.text_position_ids(n) if r.get("position_ids") is None else r["position_ids"] for r, n in zip(requests, cache_len)]
         next_pos = [int(p.max()) + 1 for p in poss]
         L = (max(cache_len) + 7) // 8 * 8
-        if B > 1 and L <= self.slot_len and B * L <= self.prefill_rows:
-            # one pass over the weights for all prompts: right-padded to L rows each (causal attention keeps the padding inert)
+        if B > 1 and L <= self.slot_len and 2 * L <= self.prefill_rows:
+            # one pass over the weights for as many prompts as the activation workspace holds (all of them, normally): right-padded
+            # to L rows each (causal attention keeps the padding inert); a larger request batch takes several such passes
             D = self.config.hidden_size
-            emb = torch.zeros(B * L, D, dtype=torch.bfloat16, device=self.device)
-            pos = torch.zeros(3, B * L, dtype=torch.int32)
-            for b, (r, n, p) in enumerate(zip(requests, cache_len, poss)):
-                e = r.get("inputs_embeds")
-                emb[b * L:b * L + n] = self.embed_tokens(r["prompt_token_ids"]) if e is None else e.to(self.device, torch.bfloat16)
-                pos[:, b * L:b * L + n] = p.to(torch.int32)
-                pos[:, b * L + n:(b + 1) * L] = next_pos[b] + torch.arange(L - n, dtype=torch.int32)
-            pos = pos.to(self.device).contiguous()
-            hid = torch.empty(B * L, D, dtype=torch.bfloat16, device=self.device)
+            per = min(B, self.prefill_rows // L)
             logits = torch.empty(B, self.config.vocab_size, dtype=torch.bfloat16, device=self.device)
-            lens = (ctypes.c_int * B)(*cache_len)
-            _hip.check(self._L.td_qwen2_prefill_batch(self._h, B, L, None, _hip.ptr(emb), _hip.ptr(pos), ctypes.cast(lens, ctypes.c_void_p),
-                                                      _hip.ptr(hid), _hip.ptr(logits), _hip.stream_ptr()))
-            for b, n in enumerate(cache_len):
-                res[b]["prompt_hidden_states"] = hid[b * L:b * L + n]
+            for b0 in range(0, B, per):
+                nb = min(per, B - b0)
+                emb = torch.zeros(nb * L, D, dtype=torch.bfloat16, device=self.device)
+                pos = torch.zeros(3, nb * L, dtype=torch.int32)
+                for j in range(nb):
+                    r, n, p = requests[b0 + j], cache_len[b0 + j], poss[b0 + j]
+                    e = r.get("inputs_embeds")
+                    emb[j * L:j * L + n] = self.embed_tokens(r["prompt_token_ids"]) if e is None else e.to(self.device, torch.bfloat16)
+                    pos[:, j * L:j * L + n] = p.to(torch.int32)
+                    pos[:, j * L + n:(j + 1) * L] = next_pos[b0 + j] + torch.arange(L - n, dtype=torch.int32)
+                pos = pos.to(self.device).contiguous()
+                hid = torch.empty(nb * L, D, dtype=torch.bfloat16, device=self.device)
+                lens = (ctypes.c_int * nb)(*cache_len[b0:b0 + nb])
+                _hip.check(self._L.td_qwen2_prefill_batch_at(self._h, b0, nb, L, None, _hip.ptr(emb), _hip.ptr(pos), ctypes.cast(lens, ctypes.c_void_p),
+                                                             _hip.ptr(hid), _hip.ptr(logits[b0:b0 + nb]), _hip.stream_ptr()))
+                for j in range(nb):
+                    res[b0 + j]["prompt_hidden_states"] = hid[j * L:j * L + cache_len[b0 + j]]
         else:
             rows = []
             for b, (r, p) in enumerate(zip(requests, poss)):

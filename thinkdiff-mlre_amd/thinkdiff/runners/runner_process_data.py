@@ -21,9 +21,23 @@ class _Loader:
     def __len__(self):
         return (len(self.order) + self.batch_size - 1) // self.batch_size
 
+    def _batch(self, s):
+        return self.dataset.collater([self.dataset[i] for i in self.order[s:s + self.batch_size]])
+
     def __iter__(self):
-        for s in range(0, len(self.order), self.batch_size):
-            yield self.dataset.collater([self.dataset[i] for i in self.order[s:s + self.batch_size]])
+        """The next batch is read and decoded on a background thread while the caller works on the current one (tar reads and
+        JPEG decoding release the GIL)."""
+        from concurrent.futures import ThreadPoolExecutor
+        starts = list(range(0, len(self.order), self.batch_size))
+        if not starts:
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(self._batch, starts[0])
+            for k in range(len(starts)):
+                cur = nxt.result()
+                if k + 1 < len(starts):
+                    nxt = pool.submit(self._batch, starts[k + 1])
+                yield cur
 
 
 @registry.register_runner("runner_process_data")

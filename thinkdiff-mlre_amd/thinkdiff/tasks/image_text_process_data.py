@@ -22,6 +22,17 @@ def flatten_dict(d, parent_key="", sep="."):
     return items
 
 
+class _CompactTensor:
+    """A row range of a batch-wide host tensor, serialised on a writer thread: torch.save of a view would write the whole
+    storage, so the clone (the reference's `.cpu().clone()`, thinkdiff/tasks/image_text_process_data.py:108-112) happens there."""
+
+    def __init__(self, view):
+        self.view = view
+
+    def save(self, buf):
+        torch.save(self.view.clone(), buf)
+
+
 @registry.register_task("image_text_process_data")
 class ImageTextProcessDataTask(BaseTask):
     def build_datasets(self, cfg):
@@ -43,13 +54,30 @@ class ImageTextProcessDataTask(BaseTask):
         assert output_shard_path
         os.makedirs(output_shard_path[0], exist_ok=True)
         pattern = os.path.join(output_shard_path[0], output_shard_path[1])
+        from concurrent.futures import ThreadPoolExecutor
+        from ..datasets.wds_io import encode_sample
         n_written = 0
-        with ShardWriter(pattern, maxsize=maxsize, start_shard=output_shard_path[2]) as writer:
+        workers = max(1, int(os.environ.get("TD_PRECOMPUTE_WRITER_THREADS", min(16, os.cpu_count() or 1))))
+        with ShardWriter(pattern, maxsize=maxsize, start_shard=output_shard_path[2]) as writer, \
+                ThreadPoolExecutor(max_workers=workers) as encoders, ThreadPoolExecutor(max_workers=1) as tar_thread:
+
+            def write_batch(records):
+                # JPEG / torch.save / json encoding in parallel, the tar appended in sample order by this one thread
+                for enc in encoders.map(encode_sample, records):
+                    writer.write(enc)
+
+            pending = None
             for samples in data_loader:
                 batch = len(samples["images"])
                 output = model(samples)
                 embeds = flatten_dict(output["generated_embed"]) if output.get("generated_embed") is not None else None
+                host = {}
+                if embeds is not None:
+                    for k, v in embeds.items():     # ONE device->host copy per embedding kind, split back into per-sample views
+                        rows = [int(t.shape[0]) for t in v]
+                        host[k] = torch.split(torch.cat(list(v)).cpu(), rows) if rows else []
                 tok = output["generated_token"]
+                records = []
                 for i in range(batch):
                     js = samples["jsons"][i]
                     js["generated_text"] = output["generated_text"][i]
@@ -58,14 +86,15 @@ class ImageTextProcessDataTask(BaseTask):
                     js["output_text"] = tok["output_text"][i]
                     js["output_token_ids"] = list(tok["output_token_ids"][i])
                     rec = {"__key__": samples["filenames"][i], "jpg": samples["images"][i][0], "json": js}
-                    if embeds is not None:
-                        for k, v in embeds.items():
-                            buf = io.BytesIO()
-                            torch.save(v[i].cpu().clone(), buf)
-                            rec[f"{k}.pth"] = buf.getvalue()
-                    writer.write(rec)
-                    n_written += 1
-            shards = None
+                    for k, v in host.items():
+                        rec[f"{k}.pth"] = _CompactTensor(v[i])
+                    records.append(rec)
+                if pending is not None:
+                    pending.result()                 # at most one batch of records in flight behind the model
+                pending = tar_thread.submit(write_batch, records)
+                n_written += batch
+            if pending is not None:
+                pending.result()
         return {"samples": n_written, "shards": writer.shards}
 
     def train_epoch(self, epoch, model, data_loader, output_shard_path=None, **kw):
