@@ -67,6 +67,8 @@ class LvlmFluxDriver:
         self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"))
         self.pipe.images_in_flight = max(1, int(run.get("images_in_flight", 2)))
         self.pipe.set_progress_bar_config(disable=False)
+        from concurrent.futures import ThreadPoolExecutor
+        self._saver, self._pending_saves = ThreadPoolExecutor(max_workers=2), []
 
     def pooled_empty_prompt(self):
         """encode_prompt(prompt="", prompt_embeds=...) computes only the CLIP pooled vector (reference :173-178)."""
@@ -87,10 +89,19 @@ class LvlmFluxDriver:
                              height=h, width=w, num_inference_steps=steps, guidance_scale=run.get("guidance_scale", 3.5), latents=lat).images
         for i, image in zip(members, outs):
             path = f"{out_dir}/{names[i]}_output_embed_flux_0.png"
-            image.save(path, format="PNG", compress_level=1)
-            print(f"Saved image to {path}")
+            self._pending_saves.append(self._saver.submit(self._save_png, image, path))   # PNG encoding overlaps the next group's GPU work
             written.append(path)
         return written
+
+    @staticmethod
+    def _save_png(image, path):
+        image.save(path, format="PNG", compress_level=1)
+        print(f"Saved image to {path}")
+
+    def _drain_saves(self):
+        for f in self._pending_saves:
+            f.result()
+        self._pending_saves.clear()
 
     def run(self):
         run = self.cfg.run_cfg
@@ -114,6 +125,7 @@ class LvlmFluxDriver:
                 print(lm_in[0].shape, answers[i], generated[0], sep="\n")
                 gen = torch.Generator(device=self.pipe._execution_device).manual_seed(int(seed))
                 written += self._render([i], {i: lm_in[0]}, pooled, names, out_dir, gens=[gen])
+            self._drain_saves()
             every = dp.gather_results(written)
             return every if every is not None else written
         images = [[Image.open(u).convert("RGB")] for u in urls]
@@ -133,6 +145,7 @@ class LvlmFluxDriver:
                 groups.setdefault(language_model_inputs[i].shape[0], []).append(i)
             for members in groups.values():
                 written += self._render(members, language_model_inputs, pooled, names, out_dir)
+        self._drain_saves()
         return written
 
 
