@@ -93,6 +93,10 @@ int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const vo
  * 35 MB hand-off workspace, so make it before capturing into a hipGraph), 1 = one workgroup per item for every shape, 2 = the
  * persistent form without the XCD-aware range order.  1 and 2 exist for in-process A/B measurements.  Returns the previous value. */
 int td_attention_set_variant(int variant);
+/* KV-cached decode attention (Sq = 1): q heads of one kv head handled per workgroup.  0 = automatic (the largest divisor of
+ * Hq / Hkv among 7, 6, 4, 3, 2 that still gives every CU a workgroup, else 1); a divisor forces it (tests, A/B).  Returns the
+ * previous value. */
+int td_attention_decode_set_group(int g);
 
 /* ---- row kernels (each is also used inside the FLUX engine) -------------------------------------- */
 

@@ -174,6 +174,33 @@ def test_batched_decode_of_forty_sequences(hip):
         assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
 
 
+@pytest.mark.parametrize("Hq,Hkv,G", [(7, 1, 7), (6, 1, 6), (6, 2, 3), (4, 2, 2), (4, 1, 4)])
+def test_decode_attention_groups_q_heads_of_a_kv_head(hip, Hq, Hkv, G):
+    """td_attention_decode_set_group: one workgroup serves G q heads of a kv head (K/V read once).  The batched decode step of a
+    decoder with Hq / Hkv q heads per kv head gives the same hidden states and logits with the forced group as with one head
+    per workgroup (the automatic choice needs >= 256 workgroups, i.e. large batches of a full-size model)."""
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    tc = Qwen2VLTextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=Hq, num_key_value_heads=Hkv, intermediate_size=1024, vocab_size=1024)
+    e = Qwen2VLTextEngine(tc, max_model_len=64, n_slots=5).init_random(3)
+    g = torch.Generator().manual_seed(2)
+    lens = [9, 33, 1, 20, 47]
+    for b, n in enumerate(lens):
+        e.forward(e.text_position_ids(n), torch.randint(0, 1024, (n,), generator=g).to(torch.int32), slot=b)
+    toks = torch.randint(0, 1024, (5,), generator=g).tolist()
+    pos = torch.tensor([lens] * 3, dtype=torch.int32)
+    outs = {}
+    for grp in (1, G):
+        prev = hip.lib().td_attention_decode_set_group(grp)
+        try:
+            h, lg = e.decode_batch(toks, pos, lens)
+            torch.cuda.synchronize()
+            outs[grp] = (h.clone(), lg.clone())
+        finally:
+            hip.lib().td_attention_decode_set_group(prev)
+    assert torch.isfinite(outs[G][0].float()).all()
+    assert _rel(outs[G][0], outs[1][0]) < 2e-3 and _rel(outs[G][1], outs[1][1]) < 2e-3
+
+
 def test_batched_prefill_in_several_passes(hip):
     """A request batch whose padded prompts exceed the activation workspace (40 x 64 rows against 256) is prefilled four
     sequences per pass into consecutive cache slots (td_qwen2_prefill_batch_at): same states as one request at a time."""

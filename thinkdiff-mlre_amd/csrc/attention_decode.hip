@@ -7,6 +7,8 @@
 // online-softmax state and output slice in registers, and the 16 slots are merged at the end (shuffles inside a wave, LDS
 // across waves).  fp32 scores / softmax / accumulation; q.k through v_dot2c_f32_bf16.
 // Semantics = td_attn_launch with Sq = 1, causal, kv_lens (keys [0, kv_lens[b]) of sequence b are visible).
+#include <atomic>
+
 #include "td_common.h"
 #include "td_kernels.h"
 
@@ -111,13 +113,37 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
 
 }  // namespace
 
+static std::atomic<int> g_decode_group{0};
+extern "C" int td_attention_decode_set_group(int g) { return g_decode_group.exchange(g); }
+
 int td_attn_decode_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.Sq == 1 && p.head_dim == 128 && p.Hq % p.Hkv == 0, "td_attn_decode: needs Sq = 1, head_dim 128");
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
   TD_CHECK_ARG(p.ldkv % 8 == 0 && ((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0 && p.q_bstride % 8 == 0 && p.kv_bstride % 8 == 0,
                "td_attn_decode: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(td_attn_decode_kernel<1>, dim3(p.Hq, p.batch), dim3(256), 0, stream, q);
+  // G q heads of one kv head per workgroup read its K/V once instead of G times (from L2); taken when the grid still gives
+  // every CU a workgroup -- many sequences -- and left at one head per workgroup for small batches
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    static std::atomic<int> cached[64] = {};
+    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cached[dev & 63].store(n, std::memory_order_relaxed);
+    if (n > 0) cus = n;
+  }
+  const int forced = g_decode_group.load(std::memory_order_relaxed);      // td_attention_decode_set_group: tests and A/B
+  int G = 1;
+  for (int g : {7, 6, 4, 3, 2})
+    if (q.q_per_kv % g == 0 && (forced ? g == forced : (long long)(p.Hq / g) * p.batch >= cus)) { G = g; break; }
+  const dim3 grid(p.Hq / G, p.batch);
+  switch (G) {
+    case 7: hipLaunchKernelGGL(td_attn_decode_kernel<7>, grid, dim3(256), 0, stream, q); break;
+    case 6: hipLaunchKernelGGL(td_attn_decode_kernel<6>, grid, dim3(256), 0, stream, q); break;
+    case 4: hipLaunchKernelGGL(td_attn_decode_kernel<4>, grid, dim3(256), 0, stream, q); break;
+    case 3: hipLaunchKernelGGL(td_attn_decode_kernel<3>, grid, dim3(256), 0, stream, q); break;
+    case 2: hipLaunchKernelGGL(td_attn_decode_kernel<2>, grid, dim3(256), 0, stream, q); break;
+    default: hipLaunchKernelGGL(td_attn_decode_kernel<1>, grid, dim3(256), 0, stream, q);
+  }
   TD_CHECK_LAUNCH();
   return 0;
 }

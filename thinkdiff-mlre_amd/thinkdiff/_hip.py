@@ -67,6 +67,7 @@ def _declare(L):
         "td_flux_trace_begin": [vp, i32],
         "td_flux_trace_end": [vp, vp, vp, vp, vp],
         "td_attention_set_variant": [i32],
+        "td_attention_decode_set_group": [i32],
         "td_quant_rows_fp8": [vp, i64, vp, i64, vp, i32, i32, vp],
         "td_linear_fp8": [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, i32, vp],
         "td_norm_rows_quant_fp8": [vp, i64, vp, i64, vp, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp],
