@@ -90,3 +90,48 @@ def test_rank_partition_of_shards_is_disjoint_and_complete(tmp_path):
     keys = [{p[i]["__key__"] for i in range(len(p))} for p in parts]
     assert keys[0].isdisjoint(keys[1]) and len(keys[0] | keys[1]) == n
     assert [len(p.shards) for p in parts] == [3, 2]
+
+
+def test_pipelined_job_keeps_sample_order_compact_tensors_and_errors(tmp_path):
+    """The job overlaps reading, the model and writing (prefetching loader, encoder threads, one tar thread): the output still holds
+    the samples in loader order, every .pth member is the compact tensor of ITS sample (not the batch-wide storage it was a view
+    of), small shards do not thrash the shard cache, and a failing model call propagates instead of hanging the writer."""
+    from thinkdiff.runners.runner_process_data import _Loader
+    from thinkdiff.tasks.image_text_process_data import ImageTextProcessDataTask
+    idx, n = _make_input_shards(str(tmp_path), n_shards=6, per_shard=4)
+    ds = CCSBUMllamaVllmProcessDatasetWids(idx)
+    assert ds.inner_dataset._cache_shards >= 6                         # a sampler chunk (1000 samples) spans all six 4-sample shards
+    reads = []
+    orig = wds_io.read_tar_samples
+    wds_io.read_tar_samples = lambda path, decode=True: (reads.append(path), orig(path, decode))[1]
+    try:
+        loader = _Loader(ds, batch_size=5, shuffle=True, seed=3)
+        order = [s["filenames"] for s in loader]
+    finally:
+        wds_io.read_tar_samples = orig
+    assert len(reads) == 6 and sum(len(b) for b in order) == n        # every shard read exactly once
+    flat = [k for b in order for k in b]
+    out_dir = str(tmp_path / "out")
+    stats = ImageTextProcessDataTask()._train_inner_loop(0, len(loader), _StubModel(), _Loader(ds, batch_size=5, shuffle=True, seed=3),
+                                                           output_shard_path=[out_dir, "%06d.tar", 0])
+    written = [s for sh in stats["shards"] for s in wds_io.read_tar_samples(sh["url"], decode=False)]
+    assert [s["__key__"] for s in written] == flat                      # tar order = loader order across the 5 batches
+    pos_in_batch = {k: i for b in order for i, k in enumerate(b)}
+    for s in written:
+        raw = s[".model.norm.output_embed.pth"]
+        assert len(raw) < 2000                                           # 2 x 8 bf16 values + pickle framing, not the whole batch
+        t = torch.load(io.BytesIO(raw), weights_only=True)
+        assert t.shape == (2, 8) and float(t[0, 0]) == float(pos_in_batch[s["__key__"]])      # _StubModel: sample i of its batch holds the value i
+
+    class Boom(_StubModel):
+        calls = 0
+
+        def __call__(self, samples):
+            Boom.calls += 1
+            if Boom.calls == 2:
+                raise RuntimeError("model failed on the second batch")
+            return super().__call__(samples)
+    import pytest
+    with pytest.raises(RuntimeError, match="second batch"):
+        ImageTextProcessDataTask()._train_inner_loop(0, len(loader), Boom(), _Loader(ds, batch_size=5, shuffle=True, seed=3),
+                                                       output_shard_path=[str(tmp_path / "out2"), "%06d.tar", 0])
