@@ -186,6 +186,12 @@ int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, c
  * normalisation and the residual stream stay as in the bf16 path. */
 enum { TD_PRECISION_BF16 = 0, TD_PRECISION_FP8_E4M3 = 1 };
 int td_flux_set_precision(td_flux* f, int precision, void* stream);
+/* Which block Linears take the fp8 path while the precision is TD_PRECISION_FP8_E4M3 (default: all).  The rest run in bf16 from
+ * the bf16 weights: a speed / deviation-from-bf16 trade.  Parent context only; takes effect at the next step. */
+enum { TD_FP8_QKV = 1, TD_FP8_OUT = 2, TD_FP8_FF1 = 4, TD_FP8_FF2 = 8,      /* double-stream blocks: to_q|k|v (+add_*), to_out, ff.net.0, ff.net.2 */
+       TD_FP8_SINGLE_IN = 16, TD_FP8_SINGLE_OUT = 32,                        /* single-stream blocks: to_q|k|v + proj_mlp, proj_out */
+       TD_FP8_ALL_GEMMS = 63 };
+int td_flux_set_fp8_gemms(td_flux* f, unsigned mask);
 int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream);
 /* per prompt: prompt_embeds bf16 [T,joint_dim], pooled bf16 [pooled_dim], ids fp32 device [n,3]
  * (txt_ids NULL = zeros, thinkdiff/models/flux_prompt.py:119) */
@@ -270,6 +276,7 @@ void td_vae_destroy(td_vae* f);
 int td_vae_num_params(const td_vae* f);
 int td_vae_param_info(const td_vae* f, int idx, char* name_buf, int buf_len, int64_t* count);
 int td_vae_load_param(td_vae* f, const char* name, const void* src, int64_t count, void* stream);
+/* seeded synthetic decoder; std <= 0: 1 / sqrt(fan_in) weights (images with contrast), else that std for every weight and bias */
 int td_vae_init_random(td_vae* f, uint64_t seed, float std, void* stream);
 /* packed latents bf16 [(h/2)(w/2), 4*latent_channels] (h, w = latent size, h*w % 64 == 0) -> image_u8 [8h,8w,3]
  * uint8 and/or image_chw bf16 [3,8h,8w] (= vae.decode output); either may be NULL. */

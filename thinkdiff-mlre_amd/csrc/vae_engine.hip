@@ -93,7 +93,7 @@ void name_resnet(td_vae* f, const std::string& p, const Resnet& r) {
   v_add(f, p + "norm2.weight", r.n2_w, r.cout); v_add(f, p + "norm2.bias", r.n2_b, r.cout);
   v_add(f, p + "conv2.weight", r.c2_w, (int64_t)r.cout * r.cout * 9, 1, r.cout, r.cout, r.cout, r.cout);
   v_add(f, p + "conv2.bias", r.c2_b, r.cout);
-  if (r.sc_w) { v_add(f, p + "conv_shortcut.weight", r.sc_w, (int64_t)r.cout * r.cin); v_add(f, p + "conv_shortcut.bias", r.sc_b, r.cout); }
+  if (r.sc_w) { v_add(f, p + "conv_shortcut.weight", r.sc_w, (int64_t)r.cout * r.cin, 0, r.cout, r.cin); v_add(f, p + "conv_shortcut.bias", r.sc_b, r.cout); }
 }
 
 int conv3(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* res, bf16_t* y, int H, int W, int cin, int cout, int up) {
@@ -178,10 +178,10 @@ int td_vae_create(const TdVaeConfig* cfg, int max_latent_h, int max_latent_w, td
   name_resnet(f, "decoder.mid_block.resnets.1.", f->mid[1]);
   const std::string a = "decoder.mid_block.attentions.0.";
   v_add(f, a + "group_norm.weight", f->agn_w, cmid); v_add(f, a + "group_norm.bias", f->agn_b, cmid);
-  v_add(f, a + "to_q.weight", f->aq_w, (int64_t)cmid * cmid); v_add(f, a + "to_q.bias", f->aq_b, cmid);
-  v_add(f, a + "to_k.weight", f->ak_w, (int64_t)cmid * cmid); v_add(f, a + "to_k.bias", f->ak_b, cmid);
-  v_add(f, a + "to_v.weight", f->av_w, (int64_t)cmid * cmid); v_add(f, a + "to_v.bias", f->av_b, cmid);
-  v_add(f, a + "to_out.0.weight", f->ao_w, (int64_t)cmid * cmid); v_add(f, a + "to_out.0.bias", f->ao_b, cmid);
+  v_add(f, a + "to_q.weight", f->aq_w, (int64_t)cmid * cmid, 0, cmid, cmid); v_add(f, a + "to_q.bias", f->aq_b, cmid);
+  v_add(f, a + "to_k.weight", f->ak_w, (int64_t)cmid * cmid, 0, cmid, cmid); v_add(f, a + "to_k.bias", f->ak_b, cmid);
+  v_add(f, a + "to_v.weight", f->av_w, (int64_t)cmid * cmid, 0, cmid, cmid); v_add(f, a + "to_v.bias", f->av_b, cmid);
+  v_add(f, a + "to_out.0.weight", f->ao_w, (int64_t)cmid * cmid, 0, cmid, cmid); v_add(f, a + "to_out.0.bias", f->ao_b, cmid);
   for (int b = 0; b < nb; ++b) {
     const std::string ub = "decoder.up_blocks." + std::to_string(b) + ".";
     for (int r = 0; r <= cfg->layers_per_block; ++r) name_resnet(f, ub + "resnets." + std::to_string(r) + ".", f->up[b][r]);
@@ -260,7 +260,11 @@ int td_vae_init_random(td_vae* f, uint64_t seed, float std, void* stream) {
   for (const VSlot& s : f->slots) {
     const bool norm_w = s.name.find("norm") != std::string::npos && s.name.find(".weight") != std::string::npos;
     const int64_t n = s.kind == 1 ? (int64_t)s.cout * 9 * s.cin_pad : s.count;   // padded output rows stay zero
-    TDV_TRY(td_fill_normal_bf16(s.ptr, n, seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(s.ptr - f->arena + 1)), norm_w ? 0.05f : std, norm_w ? 1.0f : 0.0f, stream));
+    // std <= 0: variance-preserving weights (1 / sqrt(fan_in) for convolutions and linears, 0.02 for biases), so that a synthetic
+    // decoder maps unit-scale latents to an image with contrast instead of a flat grey one
+    float sd = std;
+    if (std <= 0.f) sd = s.cin > 0 ? 1.0f / sqrtf((float)(s.kind == 1 ? 9 * s.cin : s.cin)) : 0.02f;
+    TDV_TRY(td_fill_normal_bf16(s.ptr, n, seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(s.ptr - f->arena + 1)), norm_w ? 0.05f : sd, norm_w ? 1.0f : 0.0f, stream));
   }
   // padded input channels of conv_in must see zero weights regardless (their activations are zero anyway)
   return TD_OK;

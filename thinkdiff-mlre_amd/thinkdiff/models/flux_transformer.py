@@ -146,12 +146,18 @@ class FluxTransformer2DModel:
         _hip.check(self._L.td_flux_init_random(self._h, seed, std, _hip.stream_ptr()))
         return self
 
-    def set_precision(self, precision: str = "bf16"):
-        """"bf16" (default) or "fp8": e4m3 operands for every block GEMM (weights quantised per output channel from the
-        parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly)."""
+    FP8_GEMMS = {"qkv": 1, "out": 2, "ff1": 4, "ff2": 8, "single_in": 16, "single_out": 32}     # TD_FP8_* of include/thinkdiff_hip.h
+
+    def set_precision(self, precision: str = "bf16", fp8_gemms=None):
+        """"bf16" (default) or "fp8": e4m3 operands for the block GEMMs (weights quantised per output channel from the
+        parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly).
+        fp8_gemms: None = every block Linear, or the classes that take the fp8 path (names of FP8_GEMMS, or the bit mask);
+        the others stay bf16."""
         code = {"bf16": 0, "bfloat16": 0, "fp8": 1, "fp8_e4m3": 1, "float8_e4m3fn": 1}[str(precision).replace("torch.", "")]
         _hip.check(self._L.td_flux_set_precision(self._h, code, _hip.stream_ptr()))
-        self.precision = "fp8" if code else "bf16"
+        mask = 63 if fp8_gemms is None else (int(fp8_gemms) if isinstance(fp8_gemms, int) else sum(self.FP8_GEMMS[str(n)] for n in fp8_gemms))
+        _hip.check(self._L.td_flux_set_fp8_gemms(self._h, mask))
+        self.precision, self.fp8_gemms = ("fp8" if code else "bf16"), mask
         return self
 
     # ---- conditioning / schedule ----------------------------------------------------------------------

@@ -88,7 +88,8 @@ class AutoencoderKLDecoder:
             raise KeyError(f"VAE checkpoint at {root} lacks {len(missing)} decoder tensors, e.g. {missing[:3]}")
         return m
 
-    def init_random(self, seed: int = 0, std: float = 0.02):
+    def init_random(self, seed: int = 0, std: float = 0.0):
+        """Seeded synthetic decoder; std <= 0 (default): 1 / sqrt(fan_in) weights, so decoded images have contrast."""
         _hip.check(self._L.td_vae_init_random(self._h, seed, std, _hip.stream_ptr()))
         return self
 
