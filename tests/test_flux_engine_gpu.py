@@ -254,3 +254,32 @@ def test_seeded_synthetic_weights_do_not_depend_on_the_allocation(hip):
         hs.append(e.forward(e.text_position_ids(37), ids, None, 0, True, True))
     torch.cuda.synchronize()
     assert torch.equal(hs[0][0], hs[1][0]) and torch.equal(hs[0][1], hs[1][1])
+
+
+def test_full_size_synthetic_checkpoint_is_fully_drawn(hip):
+    """td_flux_init_random on the 11.9 B-element arena: a launch carries at most 2^32 - 1 work-items, and the one-thread-per-pair fill
+    used to stop after 3.3 G elements without an error, leaving every block weight zero (the model then ignored its prompt and ran
+    ~20 % faster than on real data).  A full-depth synthetic model must react to the prompt, to one latent element everywhere, and to
+    the fp8 switch."""
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, effective_scalar
+    tr = FluxTransformer2DModel(max_img_tokens=1024, max_txt_tokens=64, max_steps=2).init_random(3)
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(1024, 64, generator=g).bfloat16().cuda()
+    pe = [(0.1 * torch.randn(40, 4096, generator=g)).bfloat16().cuda() for _ in range(2)]
+    pool = torch.randn(768, generator=g).bfloat16().cuda()
+    ids = torch.zeros(1024, 3)
+    ids[:, 1], ids[:, 2] = torch.arange(1024) // 32, torch.arange(1024) % 32
+    lat2 = lat.clone()
+    lat2[0, 0] += 0.5
+    out = {}
+    for key, prec, p, x in (("base", "bf16", pe[0], lat), ("prompt", "bf16", pe[1], lat), ("latent", "bf16", pe[0], lat2), ("fp8", "fp8", pe[0], lat)):
+        tr.set_precision(prec)
+        tr.set_condition(p, pool, ids.cuda())
+        tr.set_timesteps([effective_scalar(1000.0, torch.bfloat16)], 3500.0)
+        out[key] = tr.forward_step(x, 0).float().clone()
+    torch.cuda.synchronize()
+    base = out["base"]
+    assert torch.isfinite(base).all() and float(base.pow(2).mean().sqrt()) > 0.1
+    assert _rel_rmse(out["prompt"], base) > 1e-3                                   # text reaches the image tokens through 57 joint attentions
+    assert int(((out["latent"] - base).abs().sum(1) > 0).sum()) > 512              # one latent element moves most rows, not only its own
+    assert 1e-2 < _rel_rmse(out["fp8"], base) < 0.3                                # and e4m3 operands leave their few per cent
