@@ -271,6 +271,9 @@ def main():
                              "PIL image -- the reference driver's diffusion_pipe(...).images[0]"),
                 "precision": a.precision, "images_per_rank_per_step": G, "parallelism": f"dp{world} (independent images, seed+rank)",
                 "algorithmic_pflop_per_image": flops_img / 1e15,
+                "weights_note": ("all 11.9 B parameters drawn N(0, 0.02).  Lines recorded before this note existed (round 1: 0.703, round 2 up to "
+                                 "0.736) ran with every block weight at zero -- a truncated fill launch -- which let the chip clock ~20 % higher; "
+                                 "DESIGN.md section 5"),
             },
             "whole_step_tflops_per_gpu": flops_img * G / (elapsed / a.steps) / 1e12,
         }
