@@ -64,7 +64,7 @@ class LvlmFluxDriver:
         else:
             raise FileNotFoundError("no FLUX weights: set run.local_weights.flux to a local diffusers directory or run.synthetic: true")
         self.text = providers.load_text_encoders(run, self.pipe, self.device)
-        self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"))
+        self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"), fp8_gemms=(list(run.get("flux_fp8_gemms")) if run.get("flux_fp8_gemms", None) else None))
         self.pipe.images_in_flight = max(1, int(run.get("images_in_flight", 2)))
         self.pipe.set_progress_bar_config(disable=False)
         from concurrent.futures import ThreadPoolExecutor
