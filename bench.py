@@ -30,6 +30,7 @@ T_TXT = 193            # 65 aligner tokens + 128 T5 tokens
 GUIDANCE = 3.5
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FP8_DENSE_PEAK_TFLOPS = 5000.0
+FP8_DTYPE = "fp8_e4m3 block-GEMM operands, fp32 accumulate, bf16 elsewhere"
 
 
 def flux_flops_per_forward(s_img: int, s_txt: int) -> float:
@@ -158,28 +159,208 @@ def _pmc_traffic(kernel):
     return {"traffic": None}
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one child process per GPU, env contract of
+    torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), rendezvous on 127.0.0.1.  The parent has
+    made no GPU call and makes none (a process that initialised the GPU must not start others on this pool), never execs, relays
+    rank 0's JSON line and returns non-zero if any rank failed (the others are then terminated by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        time.sleep(0.05)
+    for r in live:                                               # a rank failed: stop exactly the children we started
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    for line in procs[0].stdout.read().splitlines():             # the result line to stdout; library chatter (gloo / RCCL banners) to stderr
+        print(line, file=sys.stdout if (rc == 0 and line.startswith("{")) else sys.stderr, flush=True)
+    return rc
+
+
+class _DryRunPipeline:
+    """--dry-run: a stand-in for the HIP pipeline so the launcher / rendezvous / sharding / gather / JSON path of this file can
+    be exercised on a GPU-less box (tests/test_bench_cpu.py).  It renders nothing and its rate means nothing."""
+    transformer = None
+
+    def __call__(self, prompt_embeds, **kw):
+        from types import SimpleNamespace
+        from PIL import Image
+        time.sleep(0.01 * prompt_embeds.shape[0])
+        return SimpleNamespace(images=[Image.new("RGB", (WIDTH, HEIGHT)) for _ in range(prompt_embeds.shape[0])])
+
+
+def config5_leg(a, pipe, dist, rank, world, dev):
+    """--workload config5 (BASELINE config 5): ONE batch of `--prompts` (64) two-image-composition jobs sharded over the ranks,
+    the drivers' `run.shard_prompts` path (thinkdiff/runners/dp_inference.py): rank 0 plans the job list (one seed per job, so
+    an image does not depend on the world size) -> broadcast_work_list (RCCL one-to-all) -> jobs[rank::world] -> every rank
+    renders its share, `--in-flight` images at a time -> gather_results (all-to-one) of (job, bytes rendered) in job order.
+    A step = the whole batch; value = prompts / wall time, scaling "strong".  Reference semantics:
+    runs/test_thinkdiff_clip_two_images.sh, scripts/test/test_mllama_t5_decoder_flux.py:57-65 (every rank the whole list)."""
+    from thinkdiff.runners.dp_inference import broadcast_work_list, gather_results, shard
+    T5, G = 258, max(1, a.in_flight)
+
+    def fence():
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if dev != "cpu":
+            torch.cuda.synchronize()
+
+    def render(jobs):
+        done = []
+        for i in range(0, len(jobs), G):
+            chunk = jobs[i:i + G]
+            pe, pooled, lat = [], [], []
+            for _, seed in chunk:
+                g = torch.Generator().manual_seed(seed)
+                pe.append(0.1 * torch.randn(T5, 4096, generator=g))
+                pooled.append(torch.randn(768, generator=g))
+                lat.append(torch.randn(16, HEIGHT // 8, WIDTH // 8, generator=g))
+            pe, pooled, lat = (torch.stack(x).bfloat16().to(dev) for x in (pe, pooled, lat))
+            if dev != "cpu":
+                from thinkdiff import _hip
+                lat = torch.stack([_hip.flux_pack_latents(lat[k]) for k in range(len(chunk))])
+            imgs = pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, num_images_per_prompt=1, height=HEIGHT, width=WIDTH,
+                        num_inference_steps=NUM_STEPS, guidance_scale=GUIDANCE, latents=lat, output_type="pil").images
+            assert len(imgs) == len(chunk) and imgs[0].size == (WIDTH, HEIGHT)
+            done += [(j, WIDTH * HEIGHT * 3) for j, _ in chunk]
+        return done
+
+    for _ in range(a.warmup):                                       # warm-up = one chunk per rank, not a whole batch
+        render([(-1, 7 + rank)] * G)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        plan = [(j, 4242 + j) for j in range(a.prompts)] if rank == 0 else None
+        jobs = shard(broadcast_work_list(plan), rank, world)
+        got = gather_results(render(jobs))
+        if rank == 0:
+            assert [j for j, _ in got] == list(range(a.prompts)), "gathered results are not the planned job list"
+    fence()
+    return time.perf_counter() - t0
+
+
+def side_workload(a, dist, rank, world, dev):
+    """Everything that is not the driver's headline run: --workload config5 (real pipeline, fp8 by default) and --dry-run of either
+    workload (stub pipeline on the CPU, gloo).  Same protocol as the headline: W warm-up steps, K timed steps between
+    barrier + synchronize on both sides, MAX over ranks, one JSON line from rank 0."""
+    if a.dry_run:
+        pipe = _DryRunPipeline()
+    else:
+        from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
+        pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=512, max_steps=32)
+        pipe.transformer.set_precision(a.precision)
+        pipe.images_in_flight = max(1, a.in_flight)
+    G = max(1, a.in_flight)
+    if a.workload == "config5":
+        elapsed = config5_leg(a, pipe, dist, rank, world, dev)
+        images, T, scaling = a.steps * a.prompts, 258, "strong"
+        workload = (f"BASELINE config 5: ThinkDiff-CLIP two-image composition, ONE batch of {a.prompts} prompts sharded over {world} rank(s) "
+                    "(rank 0 plans -> broadcast -> jobs[rank::world] -> gather), T_txt=258 (2 x 65 aligner + 128 T5), joint S=4354, FLUX.1-dev shape, "
+                    f"1024x1024, 28 steps, denoise + VAE decode + uint8/PIL, {G} images in flight per rank; a step = the whole batch")
+    else:                                                            # dry run of the headline protocol
+        pe = torch.zeros(G, T_TXT, 4096)
+
+        def fence():
+            if dist is not None:
+                dist.barrier()
+        for _ in range(a.warmup):
+            pipe(prompt_embeds=pe)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = pipe(prompt_embeds=pe).images
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert len(out) == G
+        images, T, scaling = world * a.steps * G, T_TXT, "weak"
+        workload = "BASELINE config 2 protocol with a stub pipeline"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        fl = NUM_STEPS * flux_flops_per_forward(4096, T)
+        res = {"metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X", "value": images / elapsed, "unit": "images/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+               "scaling": scaling, "vs_baseline": None,
+               "dtype": "bf16" if a.precision == "bf16" else FP8_DTYPE,
+               "data": "synthetic" if not a.dry_run else "none (dry run: stub pipeline on the CPU, gloo; the rate is meaningless)",
+               "config": {"workload": workload, "precision": a.precision, "images_per_rank_per_step": G if a.workload == "config2" else None,
+                          "prompts": a.prompts if a.workload == "config5" else None,
+                          "parallelism": f"dp{world} (" + ("sharded job list" if a.workload == "config5" else "independent images, seed+rank") + ")"},
+               "dry_run": bool(a.dry_run)}
+        if not a.dry_run:
+            res["whole_step_tflops"] = fl * images / elapsed / 1e12
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="images per rank in the timed region")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; 1 for --workload config5)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip the per-launch HIP-event trace (roofline leg)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="independent images advanced concurrently per rank (engine contexts on separate streams); a step = this many images")
-    ap.add_argument("--precision", choices=("bf16", "fp8"), default="bf16",
-                    help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path")
+    ap.add_argument("--precision", choices=("bf16", "fp8"), default=None,
+                    help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path "
+                         "(the default of --workload config5)")
     ap.add_argument("--no-fp8-leg", action="store_true",
                     help="skip the short fp8 measurement of BASELINE config 5's shape that the default bf16 run appends as the `fp8` sub-object")
+    ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
+                    help="config2 = the headline (every rank its own images, weak scaling); config5 = one batch of --prompts two-image "
+                         "compositions sharded over the ranks (strong scaling)")
+    ap.add_argument("--prompts", type=int, default=64, help="batch size of --workload config5")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo backend and a stub pipeline; exercises the launcher, rendezvous, sharding and JSON path only")
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 1 if a.workload == "config5" else 3
+    if a.precision is None:
+        a.precision = "fp8" if a.workload == "config5" else "bf16"
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))      # BEFORE anything touches the GPU in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` bare (it spawns its ranks) or under "
+                         "torch.distributed.run --nproc-per-node N")
+    if os.environ.get("TD_BENCH_FAIL_RANK") == str(rank):       # tests/test_bench_cpu.py: a rank that dies before the rendezvous
+        raise SystemExit(f"rank {rank}: failing on request (TD_BENCH_FAIL_RANK)")
+    dev = "cpu" if a.dry_run else "cuda"
+    if not a.dry_run:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("TD_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box rehearse the RCCL path
         import torch.distributed as dist
@@ -187,7 +368,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if a.dry_run or a.workload == "config5":
+        return side_workload(a, dist, rank, world, dev)
 
     from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
     pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=512, max_steps=32)

@@ -1,0 +1,57 @@
+"""bench.py's own process management, without a GPU: `python bench.py --gpus 2 --dry-run` must start its two ranks itself
+(no torch.distributed.run around it), rendezvous on 127.0.0.1 over gloo, and print exactly one JSON line from rank 0 -- the
+round-2 driver could not get a scaling curve because bench.py refused to run unless something else had started its ranks."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300, env=e)
+
+
+def _line(p):
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bare_gpus_2_spawns_its_own_ranks():
+    r = _line(_run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"))
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and r["dry_run"] is True
+    assert r["metric"].startswith("images/sec") and r["value"] > 0 and r["vs_baseline"] is None
+    assert abs(r["value"] - 2 * 2 * r["config"]["images_per_rank_per_step"] / (r["ms_per_step"] * 2 / 1e3)) < 1e-6 * r["value"]
+
+
+def test_config5_batch_is_sharded_and_gathered_in_order():
+    r = _line(_run("--gpus", "2", "--dry-run", "--workload", "config5", "--prompts", "9", "--in-flight", "2"))
+    assert r["scaling"] == "strong" and r["config"]["prompts"] == 9 and r["n_gpus"] == 2 and r["steps"] == 1
+    assert r["dtype"].startswith("fp8")                     # config 5 names the fp8 path
+    assert abs(r["value"] - 9 / (r["ms_per_step"] / 1e3)) < 1e-6 * r["value"]
+
+
+def test_runs_under_an_external_launcher_too():
+    """The driver's form: torch.distributed.run sets RANK/WORLD_SIZE, bench.py must then NOT spawn again."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_a_failing_rank_fails_the_launcher():
+    p = _run("--gpus", "2", "--dry-run", env={"TD_BENCH_FAIL_RANK": "1"})
+    assert p.returncode != 0 and "rank 1 exited" in p.stderr and not p.stdout.strip()
+
+
+def test_world_size_mismatch_is_an_error():
+    p = _run("--gpus", "2", "--dry-run", env={"RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
