@@ -119,7 +119,8 @@ int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0, "td_norm_rows: row strides must be multiples of 8");
   TD_CHECK_ARG((p.scaleA == nullptr) == (p.shiftA == nullptr), "td_norm_rows: shift and scale come together");
   if (p.q) TD_CHECK_ARG(p.q_scale && p.ldq % 8 == 0 && (uintptr_t)p.q % 8 == 0, "td_norm_rows: fp8 output needs a scale array and 8-byte aligned rows");
-  const dim3 grid((p.rows + 3) / 4), block(256);
+  TD_GRID_1D(nblk, (long long)((p.rows + 3) / 4) * 256, 256, "td_norm_rows");
+  const dim3 grid(nblk), block(256);
   switch (p.D / 512) {
 #define TD_CASE(n) case n: hipLaunchKernelGGL(td_norm_rows_kernel<n>, grid, block, 0, stream, p); break;
     TD_CASE(1) TD_CASE(2) TD_CASE(3) TD_CASE(4) TD_CASE(5) TD_CASE(6) TD_CASE(7) TD_CASE(8)
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(256) void td_qk_norm_rope_kernel(const TdQkRopePara
 int td_qk_norm_rope_launch(const TdQkRopeParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.rows > 0 && p.Hq > 0 && p.Hk >= 0, "td_qk_norm_rope: empty problem");
   TD_CHECK_ARG(p.ld % 8 == 0 && p.q_col % 8 == 0 && p.k_col % 8 == 0, "td_qk_norm_rope: columns must be 16-byte aligned");
-  hipLaunchKernelGGL(td_qk_norm_rope_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+  TD_GRID_1D(nblk, (long long)p.rows * 256, 256, "td_qk_norm_rope");
+  hipLaunchKernelGGL(td_qk_norm_rope_kernel, dim3(nblk), dim3(256), 0, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -237,8 +239,9 @@ __global__ void td_flux_rope_table_kernel(const float* ids, int S, int d0, int d
 
 int td_flux_rope_table_launch(const float* ids, int S, const int* axes, double theta, float* cosT, float* sinT, hipStream_t stream) {
   TD_CHECK_ARG(S > 0 && axes[0] + axes[1] + axes[2] == 128, "td_flux_rope_table: axes dims must sum to 128");
-  const int n = S * 64;
-  hipLaunchKernelGGL(td_flux_rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, S, axes[0], axes[1], axes[2], theta, cosT, sinT);
+  const long long n = (long long)S * 64;
+  TD_GRID_1D_I32(nblk, n, 256, "td_flux_rope_table");
+  hipLaunchKernelGGL(td_flux_rope_table_kernel, dim3(nblk), dim3(256), 0, stream, ids, S, axes[0], axes[1], axes[2], theta, cosT, sinT);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -259,7 +262,8 @@ __global__ void td_timestep_sincos_kernel(const float* t, int n, bf16_t* out) {
 
 int td_timestep_sincos_launch(const float* t, int n, bf16_t* out, hipStream_t stream) {
   TD_CHECK_ARG(n > 0, "td_timestep_sincos: n must be positive");
-  hipLaunchKernelGGL(td_timestep_sincos_kernel, dim3((n * 128 + 255) / 256), dim3(256), 0, stream, t, n, out);
+  TD_GRID_1D_I32(nblk, (long long)n * 128, 256, "td_timestep_sincos");
+  hipLaunchKernelGGL(td_timestep_sincos_kernel, dim3(nblk), dim3(256), 0, stream, t, n, out);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -279,7 +283,8 @@ __global__ void td_temb_combine_silu_kernel(const bf16_t* te, const bf16_t* ge, 
 
 int td_temb_combine_silu_launch(const bf16_t* te, const bf16_t* ge, const bf16_t* pe, int n, int D, bf16_t* temb, bf16_t* silu_out, hipStream_t stream) {
   TD_CHECK_ARG(n > 0 && D > 0, "td_temb_combine_silu: empty problem");
-  hipLaunchKernelGGL(td_temb_combine_silu_kernel, dim3((n * D + 255) / 256), dim3(256), 0, stream, te, ge, pe, n, D, temb, silu_out);
+  TD_GRID_1D_I32(nblk, (long long)n * D, 256, "td_temb_combine_silu");
+  hipLaunchKernelGGL(td_temb_combine_silu_kernel, dim3(nblk), dim3(256), 0, stream, te, ge, pe, n, D, temb, silu_out);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -298,8 +303,9 @@ __global__ void td_euler_step_kernel(bf16_t* x, const bf16_t* v, float dt, int n
 
 int td_euler_step_launch(bf16_t* x, const bf16_t* v, float dt, long long n, hipStream_t stream) {
   TD_CHECK_ARG(n > 0 && n % 8 == 0, "td_euler_step: n=%lld must be a positive multiple of 8", n);
+  TD_GRID_1D_I32(nblk, n / 8, 256, "td_euler_step");
   const int n8 = (int)(n / 8);
-  hipLaunchKernelGGL(td_euler_step_kernel, dim3((n8 + 255) / 256), dim3(256), 0, stream, x, v, dt, n8);
+  hipLaunchKernelGGL(td_euler_step_kernel, dim3(nblk), dim3(256), 0, stream, x, v, dt, n8);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -327,8 +333,8 @@ __global__ void td_flux_pack_kernel(const bf16_t* src, bf16_t* dst, int C, int H
 int td_flux_pack_launch(const bf16_t* src, bf16_t* dst, int C, int H, int W, int unpack, float div, float add, hipStream_t stream) {
   TD_CHECK_ARG(C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "td_flux_pack: bad latent shape %dx%dx%d", C, H, W);
   TD_CHECK_ARG(!unpack || div != 0.f, "td_flux_pack: scaling divisor must be non-zero");
-  const int total = C * H * W;
-  hipLaunchKernelGGL(td_flux_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, src, dst, C, H, W, unpack, div, add);
+  TD_GRID_1D_I32(nblk, (long long)C * H * W, 256, "td_flux_pack");
+  hipLaunchKernelGGL(td_flux_pack_kernel, dim3(nblk), dim3(256), 0, stream, src, dst, C, H, W, unpack, div, add);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -353,8 +359,8 @@ __global__ void td_cls_avgpool2_kernel(const bf16_t* x, bf16_t* y, int G, int C)
 
 int td_cls_avgpool2_launch(const bf16_t* x, bf16_t* y, int G, int C, hipStream_t stream) {
   TD_CHECK_ARG(G > 0 && G % 2 == 0 && C > 0, "td_cls_avgpool2: grid %d must be even", G);
-  const int total = (1 + (G / 2) * (G / 2)) * C;
-  hipLaunchKernelGGL(td_cls_avgpool2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, x, y, G, C);
+  TD_GRID_1D_I32(nblk, (1 + (long long)(G / 2) * (G / 2)) * C, 256, "td_cls_avgpool2");
+  hipLaunchKernelGGL(td_cls_avgpool2_kernel, dim3(nblk), dim3(256), 0, stream, x, y, G, C);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -374,7 +380,8 @@ __global__ void td_embed_gather_kernel(const int* ids, const bf16_t* table, bf16
 
 int td_embed_gather_launch(const int* ids, const bf16_t* table, bf16_t* out, int n, int D, int vocab, hipStream_t stream) {
   TD_CHECK_ARG(n > 0 && D % 8 == 0 && vocab > 0, "td_embed_gather: bad shape");
-  hipLaunchKernelGGL(td_embed_gather_kernel, dim3(n), dim3(256), 0, stream, ids, table, out, n, D, vocab);
+  TD_GRID_1D(nblk, (long long)n * 256, 256, "td_embed_gather");
+  hipLaunchKernelGGL(td_embed_gather_kernel, dim3(nblk), dim3(256), 0, stream, ids, table, out, n, D, vocab);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -396,7 +403,8 @@ __global__ void td_silu_mul_kernel(const bf16_t* gu, bf16_t* out, int rows, int 
 int td_silu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, hipStream_t stream) {
   TD_CHECK_ARG(rows > 0 && I % 8 == 0, "td_silu_mul: bad shape");
   const long long n = (long long)rows * (I / 8);
-  hipLaunchKernelGGL(td_silu_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, out, rows, I);
+  TD_GRID_1D(nblk, n, 256, "td_silu_mul");
+  hipLaunchKernelGGL(td_silu_mul_kernel, dim3(nblk), dim3(256), 0, stream, gu, out, rows, I);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -419,7 +427,8 @@ __global__ void td_mrope_table_kernel(const int* pos, int n, int s0, int s1, flo
 
 int td_mrope_table_launch(const int* pos, int n, const int* sections, float theta, int round_bf16, float* cosT, float* sinT, hipStream_t stream) {
   TD_CHECK_ARG(n > 0 && sections[0] + sections[1] + sections[2] == 64, "td_mrope_table: sections must sum to 64");
-  hipLaunchKernelGGL(td_mrope_table_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, stream, pos, n, sections[0], sections[1], theta, round_bf16, cosT, sinT);
+  TD_GRID_1D_I32(nblk, (long long)n * 64, 256, "td_mrope_table");
+  hipLaunchKernelGGL(td_mrope_table_kernel, dim3(nblk), dim3(256), 0, stream, pos, n, sections[0], sections[1], theta, round_bf16, cosT, sinT);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -465,7 +474,8 @@ __global__ __launch_bounds__(256) void td_norm_rows_generic_kernel(const bf16_t*
 int td_norm_rows_generic_launch(const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows, int D, int rms, float eps,
                                 const bf16_t* w, const bf16_t* b, hipStream_t stream) {
   TD_CHECK_ARG(rows > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "td_layernorm: D and strides must be multiples of 8");
-  hipLaunchKernelGGL(td_norm_rows_generic_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, y, ldy, rows, D, rms, eps, w, b);
+  TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_norm_rows_generic");
+  hipLaunchKernelGGL(td_norm_rows_generic_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, y, ldy, rows, D, rms, eps, w, b);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -487,7 +497,8 @@ __global__ void td_add_rows_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out
 int td_add_rows_launch(const bf16_t* a, const bf16_t* b, bf16_t* out, int rows, int D, int b_rows, hipStream_t stream) {
   TD_CHECK_ARG(rows > 0 && D % 8 == 0 && b_rows > 0, "td_add_rows: bad shape");
   const long long n8 = (long long)rows * D / 8;
-  hipLaunchKernelGGL(td_add_rows_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, a, b, out, n8, D / 8, b_rows);
+  TD_GRID_1D(nblk, n8, 256, "td_add_rows");
+  hipLaunchKernelGGL(td_add_rows_kernel, dim3(nblk), dim3(256), 0, stream, a, b, out, n8, D / 8, b_rows);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -512,7 +523,8 @@ __global__ void td_glu_mul_kernel(const bf16_t* gu, bf16_t* out, int rows, int I
 int td_glu_mul_launch(const bf16_t* gu, bf16_t* out, int rows, int I, int act, hipStream_t stream) {
   TD_CHECK_ARG(rows > 0 && I % 8 == 0, "td_glu_mul: bad shape");
   const long long n = (long long)rows * (I / 8);
-  hipLaunchKernelGGL(td_glu_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, out, rows, I, act);
+  TD_GRID_1D(nblk, n, 256, "td_glu_mul");
+  hipLaunchKernelGGL(td_glu_mul_kernel, dim3(nblk), dim3(256), 0, stream, gu, out, rows, I, act);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -539,7 +551,8 @@ __global__ void td_rope_half_kernel(bf16_t* x, int ldx, int S, int H, int head_s
 int td_rope_half_launch(bf16_t* x, int ldx, int S, int H, int head_stride, int hd, const float* cs, const float* sn, hipStream_t stream) {
   TD_CHECK_ARG(S > 0 && H > 0 && hd % 4 == 0 && hd <= head_stride && head_stride % 2 == 0 && ldx % 2 == 0, "td_rope_half: bad shape");
   const long long n = (long long)S * H * (hd / 4);
-  hipLaunchKernelGGL(td_rope_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ldx, S, H, head_stride, hd, cs, sn);
+  TD_GRID_1D(nblk, n, 256, "td_rope_half");
+  hipLaunchKernelGGL(td_rope_half_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, S, H, head_stride, hd, cs, sn);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -563,7 +576,8 @@ __global__ void td_patchify_kernel(const void* pix, int src_f32, int C, int H, i
 
 int td_patchify_launch(const void* pix, int src_f32, int C, int H, int W, int p, bf16_t* out, int Kpad, hipStream_t stream) {
   TD_CHECK_ARG(C > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= C * p * p, "td_patchify: image %dx%d is not a multiple of the patch %d, or Kpad too small", H, W, p);
-  hipLaunchKernelGGL(td_patchify_kernel, dim3((H / p) * (W / p)), dim3(256), 0, stream, pix, src_f32, C, H, W, p, out, Kpad);
+  TD_GRID_1D(nblk, (long long)(H / p) * (W / p) * 256, 256, "td_patchify");
+  hipLaunchKernelGGL(td_patchify_kernel, dim3(nblk), dim3(256), 0, stream, pix, src_f32, C, H, W, p, out, Kpad);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -595,7 +609,8 @@ __global__ void td_qwen2_patchify_u8_kernel(const unsigned char* img, int H, int
 int td_qwen2_patchify_u8_launch(const unsigned char* img, int H, int W, const float* lut, int p, int m, int T, bf16_t* out, int Kpad, hipStream_t stream) {
   TD_CHECK_ARG(img && lut && out && p > 0 && m > 0 && T > 0 && H > 0 && W > 0 && H % (p * m) == 0 && W % (p * m) == 0 && Kpad >= 3 * T * p * p,
                "td_qwen2_patchify_u8: image %dx%d is not a multiple of patch x merge = %d, or Kpad too small", H, W, p * m);
-  hipLaunchKernelGGL(td_qwen2_patchify_u8_kernel, dim3((H / p) * (W / p)), dim3(256), 0, stream, img, H, W, lut, p, m, T, out, Kpad);
+  TD_GRID_1D(nblk, (long long)(H / p) * (W / p) * 256, 256, "td_qwen2_patchify_u8");
+  hipLaunchKernelGGL(td_qwen2_patchify_u8_kernel, dim3(nblk), dim3(256), 0, stream, img, H, W, lut, p, m, T, out, Kpad);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -613,7 +628,8 @@ __global__ void td_cast_pad_rows_kernel(const void* src, int src_f32, int rows, 
 int td_cast_pad_rows_launch(const void* src, int src_f32, int rows, int K, bf16_t* out, int Kpad, hipStream_t stream) {
   TD_CHECK_ARG(rows > 0 && K > 0 && Kpad >= K, "td_cast_pad_rows: bad shape");
   const long long n = (long long)rows * Kpad;
-  hipLaunchKernelGGL(td_cast_pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, src_f32, rows, K, out, Kpad);
+  TD_GRID_1D(nblk, n, 256, "td_cast_pad_rows");
+  hipLaunchKernelGGL(td_cast_pad_rows_kernel, dim3(nblk), dim3(256), 0, stream, src, src_f32, rows, K, out, Kpad);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -634,7 +650,8 @@ __global__ void td_vision_rope_table_kernel(const int* pos, int S, int hd, float
 
 int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, float* cs, float* sn, hipStream_t stream) {
   TD_CHECK_ARG(pos && cs && sn && S > 0 && hd % 4 == 0, "td_vision_rope_table: bad arguments");
-  hipLaunchKernelGGL(td_vision_rope_table_kernel, dim3((S * (hd / 2) + 255) / 256), dim3(256), 0, stream, pos, S, hd, theta, cs, sn);
+  TD_GRID_1D_I32(nblk, (long long)S * (hd / 2), 256, "td_vision_rope_table");
+  hipLaunchKernelGGL(td_vision_rope_table_kernel, dim3(nblk), dim3(256), 0, stream, pos, S, hd, theta, cs, sn);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -695,7 +712,8 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t
 
 int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream) {
   TD_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_fp8: bad arguments");
-  const dim3 grid((rows + 3) / 4), block(256);
+  TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_quant_rows_fp8");
+  const dim3 grid(nblk), block(256);
   switch (K % 512 == 0 ? K / 512 : 0) {
 #define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows); break;
     TD_CASE(1) TD_CASE(2) TD_CASE(4) TD_CASE(6) TD_CASE(8) TD_CASE(24) TD_CASE(30)

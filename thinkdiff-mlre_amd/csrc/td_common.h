@@ -94,3 +94,24 @@ void td_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 #define TD_CHECK_LAUNCH() TD_CHECK_HIP(hipGetLastError())
+
+// ---- launch geometry -------------------------------------------------------
+// A dispatch packet carries the grid as 32-bit WORK-ITEM counts: blocks x threads-per-block must stay below 2^32, and a larger
+// product is truncated WITHOUT an error (round 2: td_fill_normal drew 3.3 G of 11.9 G weights that way).  Every launcher that
+// derives its grid from an element count goes through td_grid_1d / TD_GRID_1D: the count either fits or the call is refused
+// with TD_ERR_INVALID; kernels that must take more walk a grid-stride loop (td_fill_normal_kernel) and cap their grid themselves.
+inline bool td_grid_1d(long long items, int block, unsigned* blocks) {
+  if (items <= 0 || block <= 0) return false;
+  const long long b = (items + block - 1) / block;
+  if (b * block >= (1ll << 32)) return false;
+  *blocks = (unsigned)b;
+  return true;
+}
+#define TD_GRID_1D(var, items, block, what)                                                                                   \
+  unsigned var = 0;                                                                                                           \
+  TD_CHECK_ARG(td_grid_1d((long long)(items), (block), &var),                                                                 \
+               "%s: %lld work-items in blocks of %d do not fit one launch (grid x block must stay below 2^32)", what, (long long)(items), (int)(block))
+// for kernels that index their work-items with a 32-bit int
+#define TD_GRID_1D_I32(var, items, block, what)                                                                               \
+  TD_CHECK_ARG((long long)(items) < (1ll << 31), "%s: %lld work-items exceed the kernel's 32-bit index", what, (long long)(items)); \
+  TD_GRID_1D(var, items, block, what)

@@ -122,7 +122,8 @@ int td_groupnorm_nhwc_launch(const bf16_t* x, bf16_t* y, int P, int C, int G, fl
   hipLaunchKernelGGL(td_gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, x, P, C, G, ppb, partial);
   hipLaunchKernelGGL(td_gn_finalize_kernel, dim3(G), dim3(64), 0, stream, partial, nblocks, G, (double)P * (C / G), eps, stats);
   const long long n8 = (long long)P * C / 8;
-  hipLaunchKernelGGL(td_gn_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, x, y, n8, C, G, stats, gamma, beta, silu);
+  TD_GRID_1D(nblk_apply, n8, 256, "td_groupnorm_nhwc");
+  hipLaunchKernelGGL(td_gn_apply_kernel, dim3(nblk_apply), dim3(256), 0, stream, x, y, n8, C, G, stats, gamma, beta, silu);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(256) void td_softmax_rows_kernel(const float* s, bf
 
 int td_softmax_rows_launch(const float* s, bf16_t* p, int rows, int cols, float scale, hipStream_t stream) {
   TD_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "td_softmax_rows: cols=%d must be a positive multiple of 4", cols);
-  hipLaunchKernelGGL(td_softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, s, p, cols, scale);
+  TD_GRID_1D(nblk, (long long)rows * 256, 256, "td_softmax_rows");
+  hipLaunchKernelGGL(td_softmax_rows_kernel, dim3(nblk), dim3(256), 0, stream, s, p, cols, scale);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -184,7 +186,8 @@ __global__ void td_conv_pack_kernel(const bf16_t* w, bf16_t* out, int Cout, int 
 int td_conv_pack_launch(const bf16_t* w, bf16_t* out, int Cout, int Cin, int Cout_pad, int Cin_pad, hipStream_t stream) {
   TD_CHECK_ARG(Cout > 0 && Cin > 0 && Cout_pad >= Cout && Cin_pad >= Cin, "td_conv3x3_pack_weight: bad shape");
   const long long total = (long long)Cout_pad * 9 * Cin_pad;
-  hipLaunchKernelGGL(td_conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, out, Cout, Cin, Cout_pad, Cin_pad);
+  TD_GRID_1D(nblk, total, 256, "td_conv_pack");
+  hipLaunchKernelGGL(td_conv_pack_kernel, dim3(nblk), dim3(256), 0, stream, w, out, Cout, Cin, Cout_pad, Cin_pad);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -205,8 +208,8 @@ __global__ void td_latents_to_nhwc_kernel(const bf16_t* packed, bf16_t* out, int
 
 int td_latents_to_nhwc_launch(const bf16_t* packed, bf16_t* out, int C, int h, int w, int Cpad, float div, float add, hipStream_t stream) {
   TD_CHECK_ARG(C > 0 && h % 2 == 0 && w % 2 == 0 && Cpad >= C, "td_latents_to_nhwc: bad shape");
-  const int n = h * w * Cpad;
-  hipLaunchKernelGGL(td_latents_to_nhwc_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, packed, out, C, h, w, Cpad, div, add);
+  TD_GRID_1D_I32(nblk, (long long)h * w * Cpad, 256, "td_latents_to_nhwc");
+  hipLaunchKernelGGL(td_latents_to_nhwc_kernel, dim3(nblk), dim3(256), 0, stream, packed, out, C, h, w, Cpad, div, add);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -228,7 +231,8 @@ __global__ void td_image_finalize_kernel(const bf16_t* x, int P, int Cpad, unsig
 
 int td_image_finalize_launch(const bf16_t* x, int P, int Cpad, unsigned char* u8, bf16_t* chw, hipStream_t stream) {
   TD_CHECK_ARG(P > 0 && Cpad >= 3 && (u8 || chw), "td_image_finalize: bad arguments");
-  hipLaunchKernelGGL(td_image_finalize_kernel, dim3((P * 3 + 255) / 256), dim3(256), 0, stream, x, P, Cpad, u8, chw);
+  TD_GRID_1D_I32(nblk, (long long)P * 3, 256, "td_image_finalize");
+  hipLaunchKernelGGL(td_image_finalize_kernel, dim3(nblk), dim3(256), 0, stream, x, P, Cpad, u8, chw);
   TD_CHECK_LAUNCH();
   return 0;
 }

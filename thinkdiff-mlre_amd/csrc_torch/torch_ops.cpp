@@ -5,8 +5,12 @@
 // and sizes to the C ABI of libthinkdiff_hip.so (include/thinkdiff_hip.h).  Conventions: tensors are borrowed (caller owns,
 // device-resident, innermost stride 1), outputs come from the PyTorch caching allocator on the current HIP stream, nothing
 // synchronises, a rejected argument is a TORCH_CHECK failure (Python RuntimeError) carrying td_last_error().  There is no CPU,
-// Meta or composite kernel: host tensors fail in the dispatcher instead of computing somewhere else.
+// Meta or composite kernel: a call with only host tensors fails in the dispatcher.  The dispatcher picks this kernel as soon as
+// ANY argument is on the GPU, so every tensor argument -- the optional ones too -- is checked here for device (all on x's), dtype,
+// contiguity and extent before its pointer goes to the C ABI; each op also makes x's device current for its duration (the
+// launchers read hipGetDevice() for per-device attributes and their stream-K / split-K workspaces).
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -22,13 +26,32 @@ void check_rows(const at::Tensor& t, const char* name, at::ScalarType ty = at::k
   TORCH_CHECK(t.scalar_type() == ty, "thinkdiff_hip: ", name, " has dtype ", t.scalar_type(), ", expected ", ty);
   TORCH_CHECK(t.dim() >= 1 && t.stride(-1) == 1, "thinkdiff_hip: ", name, " needs innermost stride 1");
 }
+// a per-column / per-row operand: on `like`'s device, dtype `ty`, contiguous, exactly `numel` elements
+void check_vec(const at::Tensor& t, const char* name, const at::Tensor& like, int64_t numel, at::ScalarType ty = at::kBFloat16) {
+  check_rows(t, name, ty);
+  TORCH_CHECK(t.device() == like.device(), "thinkdiff_hip: ", name, " lives on ", t.device(), ", expected ", like.device());
+  TORCH_CHECK(t.is_contiguous() && t.numel() == numel, "thinkdiff_hip: ", name, " needs ", numel, " contiguous elements, got ", t.numel());
+}
+void check_vec(const c10::optional<at::Tensor>& t, const char* name, const at::Tensor& like, int64_t numel, at::ScalarType ty = at::kBFloat16) {
+  if (t.has_value() && t->defined()) check_vec(*t, name, like, numel, ty);
+}
+void same_device(const at::Tensor& t, const char* name, const at::Tensor& like) {
+  TORCH_CHECK(t.device() == like.device(), "thinkdiff_hip: ", name, " lives on ", t.device(), ", expected ", like.device());
+}
+using DeviceGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
 void ok(int rc) { TORCH_CHECK(rc == TD_OK, "libthinkdiff_hip error ", rc, ": ", td_last_error()); }
 
 // y = act(x . w^T + bias) * gate + res      (nn.Linear and its fused neighbours)
 at::Tensor linear(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t act,
                   const c10::optional<at::Tensor>& gate, const c10::optional<at::Tensor>& res) {
-  check_rows(x, "x"); check_rows(w, "w");
+  check_rows(x, "x"); check_rows(w, "w"); same_device(w, "w", x);
   TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.is_contiguous() && w.size(1) == x.size(1), "thinkdiff_hip::linear: x [M,K], w [N,K] contiguous");
+  check_vec(bias, "bias", x, w.size(0)); check_vec(gate, "gate", x, w.size(0));
+  if (res.has_value() && res->defined()) {
+    check_rows(*res, "res"); same_device(*res, "res", x);
+    TORCH_CHECK(res->dim() == 2 && res->size(0) == x.size(0) && res->size(1) == w.size(0), "thinkdiff_hip::linear: res must be [M,N]");
+  }
+  DeviceGuard guard(x.device());
   at::Tensor y = at::empty({x.size(0), w.size(0)}, x.options());
   const int64_t ldr = res.has_value() && res->defined() ? res->stride(0) : 0;
   ok(td_linear_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), P(bias), y.data_ptr(), y.stride(0), (int)x.size(0), (int)w.size(0),
@@ -40,8 +63,12 @@ at::Tensor linear(const at::Tensor& x, const at::Tensor& w, const c10::optional<
 at::Tensor aligner_mlp2x(const at::Tensor& x, const at::Tensor& w0, const at::Tensor& b0, const at::Tensor& w2, const at::Tensor& b2,
                          const at::Tensor& norm_w, double eps, bool fp32_norm) {
   check_rows(x, "x"); check_rows(w0, "w0"); check_rows(w2, "w2");
-  TORCH_CHECK(x.dim() == 2, "thinkdiff_hip::aligner_mlp2x: x [M,K]");
+  TORCH_CHECK(x.dim() == 2 && w0.dim() == 2 && w2.dim() == 2, "thinkdiff_hip::aligner_mlp2x: x [M,K], w0 [H,K], w2 [H,H]");
   const int64_t M = x.size(0), K = x.size(1), H = w0.size(0);
+  check_vec(w0, "w0", x, H * K); check_vec(w2, "w2", x, H * H);
+  TORCH_CHECK(w0.size(1) == K && w2.size(0) == H && w2.size(1) == H, "thinkdiff_hip::aligner_mlp2x: w0 must be [H,K] and w2 [H,H]");
+  check_vec(b0, "b0", x, H); check_vec(b2, "b2", x, H); check_vec(norm_w, "norm_w", x, H);
+  DeviceGuard guard(x.device());
   at::Tensor ws = at::empty({2 * M * H}, x.options());
   at::Tensor y = at::empty({M, H}, x.options());
   ok(td_aligner_mlp2x_bf16(x.data_ptr(), x.stride(0), (int)M, (int)K, (int)H, w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(),
@@ -53,6 +80,12 @@ at::Tensor aligner_mlp2x(const at::Tensor& x, const at::Tensor& w0, const at::Te
 at::Tensor attention(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, int64_t Hq, int64_t Hkv, double scale, bool causal) {
   check_rows(q, "q"); check_rows(k, "k"); check_rows(v, "v");
   TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3 && k.strides() == v.strides(), "thinkdiff_hip::attention: q/k/v [B,S,cols], k and v with equal strides");
+  same_device(k, "k", q); same_device(v, "v", q);
+  TORCH_CHECK(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "thinkdiff_hip::attention: Hq must be a positive multiple of Hkv");
+  TORCH_CHECK(q.size(2) >= Hq * 128 && k.size(2) >= Hkv * 128 && v.size(2) >= Hkv * 128,
+              "thinkdiff_hip::attention: q needs >= Hq*128 columns and k/v >= Hkv*128 (got ", q.size(2), ", ", k.size(2), ", ", v.size(2), ")");
+  TORCH_CHECK(k.size(0) == q.size(0) && v.size(0) == q.size(0) && v.size(1) == k.size(1), "thinkdiff_hip::attention: q/k/v batch sizes and k/v lengths must agree");
+  DeviceGuard guard(q.device());
   at::Tensor o = at::empty({q.size(0), q.size(1), Hq * 128}, q.options());
   ok(td_attention_bf16(q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(1), k.stride(0), o.data_ptr(),
                        o.stride(1), o.stride(0), (int)q.size(0), (int)q.size(1), (int)k.size(1), (int)Hq, (int)Hkv, 128, (float)scale,
@@ -66,6 +99,11 @@ at::Tensor norm_rows(const at::Tensor& x, bool rms, double eps, const c10::optio
                      const c10::optional<at::Tensor>& shiftB, const c10::optional<at::Tensor>& scaleB) {
   check_rows(x, "x");
   TORCH_CHECK(x.dim() == 2, "thinkdiff_hip::norm_rows: x [rows,D]");
+  const int64_t Dn = x.size(1);
+  check_vec(w, "w", x, Dn); check_vec(shiftA, "shiftA", x, Dn); check_vec(scaleA, "scaleA", x, Dn);
+  check_vec(shiftB, "shiftB", x, Dn); check_vec(scaleB, "scaleB", x, Dn);
+  TORCH_CHECK(split >= 0 && split <= x.size(0), "thinkdiff_hip::norm_rows: split outside [0, rows]");
+  DeviceGuard guard(x.device());
   at::Tensor y = at::empty_like(x);
   ok(td_norm_rows_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), (int)x.size(0), (int)x.size(1), rms ? 1 : 0, (float)eps, P(w),
                        (int)split, P(shiftA), P(scaleA), P(shiftB), P(scaleB), stream_of(x)));
@@ -79,6 +117,12 @@ at::Tensor& qk_norm_rope_(at::Tensor& qkv, int64_t Hq, int64_t Hk, int64_t q_col
   check_rows(qkv, "qkv"); check_rows(cos, "cos", at::kFloat); check_rows(sin, "sin", at::kFloat);
   TORCH_CHECK(qkv.dim() == 2 && cos.is_contiguous() && sin.is_contiguous() && cos.size(0) == qkv.size(0) && cos.size(1) == 128,
               "thinkdiff_hip::qk_norm_rope_: qkv [rows,cols], cos/sin fp32 [rows,128]");
+  check_vec(cos, "cos", qkv, qkv.size(0) * 128, at::kFloat); check_vec(sin, "sin", qkv, qkv.size(0) * 128, at::kFloat);
+  check_vec(wqA, "wqA", qkv, 128); check_vec(wkA, "wkA", qkv, 128); check_vec(wqB, "wqB", qkv, 128); check_vec(wkB, "wkB", qkv, 128);
+  TORCH_CHECK(Hq >= 0 && Hk >= 0 && q_col >= 0 && k_col >= 0 && q_col + Hq * 128 <= qkv.size(1) && k_col + Hk * 128 <= qkv.size(1),
+              "thinkdiff_hip::qk_norm_rope_: the q / k head blocks must lie inside a row of qkv");
+  TORCH_CHECK(split >= 0 && split <= qkv.size(0), "thinkdiff_hip::qk_norm_rope_: split outside [0, rows]");
+  DeviceGuard guard(qkv.device());
   ok(td_qk_norm_rope_bf16(qkv.data_ptr(), qkv.stride(0), (int)qkv.size(0), (int)Hq, (int)Hk, (int)q_col, (int)k_col, (const float*)cos.data_ptr(),
                           (const float*)sin.data_ptr(), (int)split, P(wqA), P(wkA), wqB.has_value() && wqB->defined() ? P(wqB) : P(wqA),
                           wkB.has_value() && wkB->defined() ? P(wkB) : P(wkA), (float)eps, rotate_half ? 1 : 0, stream_of(qkv)));
@@ -89,6 +133,8 @@ at::Tensor& qk_norm_rope_(at::Tensor& qkv, int64_t Hq, int64_t Hk, int64_t q_col
 at::Tensor& euler_step_(at::Tensor& x, const at::Tensor& v, double dt) {
   check_rows(x, "x"); check_rows(v, "v");
   TORCH_CHECK(x.is_contiguous() && v.is_contiguous() && x.numel() == v.numel(), "thinkdiff_hip::euler_step_: contiguous x, v of equal size");
+  same_device(v, "v", x);
+  DeviceGuard guard(x.device());
   ok(td_euler_step_bf16(x.data_ptr(), v.data_ptr(), (float)dt, x.numel(), stream_of(x)));
   return x;
 }
@@ -97,6 +143,7 @@ at::Tensor flux_pack_latents(const at::Tensor& latents) {            // [C,H,W] 
   check_rows(latents, "latents");
   TORCH_CHECK(latents.dim() == 3 && latents.is_contiguous(), "thinkdiff_hip::flux_pack_latents: contiguous [C,H,W]");
   const int64_t C = latents.size(0), H = latents.size(1), W = latents.size(2);
+  DeviceGuard guard(latents.device());
   at::Tensor out = at::empty({(H / 2) * (W / 2), C * 4}, latents.options());
   ok(td_flux_pack_latents(latents.data_ptr(), out.data_ptr(), (int)C, (int)H, (int)W, 0, 1.0f, 0.0f, stream_of(latents)));
   return out;
@@ -105,6 +152,7 @@ at::Tensor flux_pack_latents(const at::Tensor& latents) {            // [C,H,W] 
 at::Tensor flux_unpack_latents(const at::Tensor& packed, int64_t C, int64_t H, int64_t W, double div, double add) {   // bf16(bf16(x / div) + add)
   check_rows(packed, "packed");
   TORCH_CHECK(packed.is_contiguous() && packed.numel() == C * H * W, "thinkdiff_hip::flux_unpack_latents: contiguous [(H/2)(W/2), 4C]");
+  DeviceGuard guard(packed.device());
   at::Tensor out = at::empty({C, H, W}, packed.options());
   ok(td_flux_pack_latents(packed.data_ptr(), out.data_ptr(), (int)C, (int)H, (int)W, 1, (float)div, (float)add, stream_of(packed)));
   return out;
@@ -116,6 +164,7 @@ at::Tensor cls_avgpool2(const at::Tensor& tokens) {                  // [1+G*G, 
   int64_t G = 0;
   while ((G + 1) * (G + 1) <= tokens.size(0) - 1) ++G;
   TORCH_CHECK(G * G == tokens.size(0) - 1, "thinkdiff_hip::cls_avgpool2: token count must be 1 + G*G");
+  DeviceGuard guard(tokens.device());
   at::Tensor out = at::empty({1 + (G / 2) * (G / 2), tokens.size(1)}, tokens.options());
   ok(td_cls_avgpool2_bf16(tokens.data_ptr(), out.data_ptr(), (int)G, (int)tokens.size(1), stream_of(tokens)));
   return out;
@@ -126,6 +175,7 @@ at::Tensor sample_top_p(const at::Tensor& logits, double temperature, double top
   check_rows(logits, "logits");
   at::Tensor x = logits.dim() == 1 ? logits.unsqueeze(0) : logits;
   TORCH_CHECK(x.dim() == 2, "thinkdiff_hip::sample_top_p: logits [rows, vocab]");
+  DeviceGuard guard(x.device());
   at::Tensor out = at::empty({x.size(0)}, x.options().dtype(at::kInt));
   ok(td_sample_top_p_bf16(x.data_ptr(), x.stride(0), (int)x.size(0), (int)x.size(1), (float)temperature, (float)top_p, (uint64_t)seed,
                           (uint64_t)offset, (int32_t*)out.data_ptr(), stream_of(x)));
