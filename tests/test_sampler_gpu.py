@@ -107,3 +107,24 @@ def test_generate_is_reproducible_under_torch_seed(hip):
     a = eng.generate(list(range(5, 25)), sp, generator=g)["token_ids"]
     b = eng.generate(list(range(5, 25)), sp, generator=torch.Generator().manual_seed(99))["token_ids"]
     assert a == b
+
+
+def test_infinite_and_degenerate_rows_always_yield_a_token(hip):
+    """A +inf logit holds all the mass: the sampler must return it (the first one) whatever temperature / top_p say, and rows of
+    -inf / NaN must still write a valid id (such rows left out[row] unwritten and could index LDS out of range)."""
+    vocab = 4096
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, vocab, generator=g).bfloat16()
+    x[0, 777] = float("inf")
+    x[1, 12] = float("inf"); x[1, 3000] = float("inf")
+    x[2, :] = float("-inf")
+    x[3, :] = float("nan")
+    x[4, :] = float("-inf"); x[4, 99] = 1.5
+    out = torch.full((6,), -7, dtype=torch.int32, device="cuda")
+    for o in range(4):
+        ids = hip.sample_top_p(x.cuda(), 0.6, 0.9, seed=3, offset=o)
+        torch.cuda.synchronize()
+        ids = ids.cpu()
+        assert int(ids[0]) == 777 and int(ids[1]) == 12 and int(ids[4]) == 99
+        assert all(0 <= int(i) < vocab for i in ids), ids
+    del out

@@ -36,3 +36,35 @@ def test_ops_match_the_c_abi_binding(hip):
     assert ids.dtype == torch.int32 and ids.shape == (4,)
     with pytest.raises(RuntimeError):
         O.linear(x[:, :96].contiguous(), w[:, :96].contiguous(), None, 0, None, None)       # K = 96 is not a multiple of 64: the kernel refuses
+
+
+def test_mixed_device_and_short_arguments_are_rejected(hip):
+    """The dispatcher picks the GPU kernel as soon as ANY argument is on the GPU; a host bias / gate / residual, a wrong dtype or a
+    short tensor must raise instead of reaching the kernel as a host pointer or an out-of-bounds read."""
+    import thinkdiff.ops  # noqa: F401
+    O = torch.ops.thinkdiff_hip
+    x = torch.zeros(128, 256, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(512, 256, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(512, dtype=torch.bfloat16, device="cuda")
+    for bad in (dict(bias=b.cpu()), dict(bias=b.float()), dict(bias=b[:100]), dict(gate=b.cpu()), dict(gate=b[:8]),
+                dict(res=torch.zeros(128, 512, dtype=torch.bfloat16)), dict(res=torch.zeros(64, 512, dtype=torch.bfloat16, device="cuda"))):
+        kw = dict(bias=b, gate=None, res=None)
+        kw.update(bad)
+        with pytest.raises(RuntimeError):
+            O.linear(x, w, kw["bias"], 0, kw["gate"], kw["res"])
+    w0, w2 = torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda"), torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda")
+    v = torch.zeros(256, dtype=torch.bfloat16, device="cuda")
+    O.aligner_mlp2x(x, w0, v, w2, v, v, 1e-6, False)                      # well-formed call passes
+    for args in ((x, w0, v.cpu(), w2, v, v), (x, w0, v, w2, v[:128], v), (x, w0, v, w2, v, v.float()), (x, w0[:128], v, w2, v, v),
+                 (x, w0, v, w2[:, :128].contiguous(), v, v)):
+        with pytest.raises(RuntimeError):
+            O.aligner_mlp2x(*args, 1e-6, False)
+    q = torch.zeros(1, 64, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        O.attention(q, q, q, 4, 4, 0.088, False)                           # 4 heads need 512 columns
+    with pytest.raises(RuntimeError):
+        O.attention(q, q.cpu(), q.cpu(), 2, 2, 0.088, False)
+    with pytest.raises(RuntimeError):
+        O.attention(q, q.repeat(2, 1, 1), q.repeat(2, 1, 1), 2, 2, 0.088, False)   # k/v batch differs from q's
+    with pytest.raises(RuntimeError):
+        O.norm_rows(x.repeat(1, 2).contiguous(), False, 1e-6, None, 0, v.cpu().repeat(2), v.repeat(2), None, None)

@@ -493,6 +493,11 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream) {
 
 }  // extern "C"
 
+struct FloatPack { static constexpr int N = 128; float v[N]; };
+__global__ void td_set_floats_kernel(float* dst, FloatPack vals, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
 // ---- synthetic checkpoint: counter-based N(0, std) (full-shape random init for throughput runs) ------
 // Grid-stride: a launch carries at most 2^32 - 1 work-items (the dispatch packet's grid size is 32 bits and a larger product is
 // truncated WITHOUT an error) -- the 11.9 B-parameter FLUX arena needs 5.95 G pairs.  The one-thread-per-pair form filled only
@@ -564,11 +569,20 @@ int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, vo
   TD_CHECK_ARG(f->cond_set, "td_flux_set_timesteps: call td_flux_set_condition first (temb includes the pooled text embedding)");
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D;
-  // the scalars travel as a <= 260-byte pageable H2D copy ordered on the stream; the staging vector belongs to the context and
-  // outlives the copy, so nothing here waits for the stream
-  f->tv_host.assign(t_eff, t_eff + n);
-  f->tv_host.push_back(g_eff);
-  TD_CHECK_HIP(hipMemcpyAsync(f->tvals, f->tv_host.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+  // The schedule scalars travel BY VALUE in a kernel argument (stream-ordered, no host buffer whose lifetime or reallocation
+  // could race a deferred copy); schedules longer than the pack take a synchronous copy instead.
+  if (n + 1 <= FloatPack::N) {
+    FloatPack fp;
+    for (int i = 0; i < n; ++i) fp.v[i] = t_eff[i];
+    fp.v[n] = g_eff;
+    hipLaunchKernelGGL(td_set_floats_kernel, dim3(1), dim3(FloatPack::N), 0, s, f->tvals, fp, n + 1);
+    TD_CHECK_LAUNCH();
+  } else {
+    f->tv_host.assign(t_eff, t_eff + n);
+    f->tv_host.push_back(g_eff);
+    TD_CHECK_HIP(hipMemcpyAsync(f->tvals, f->tv_host.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+    TD_CHECK_HIP(hipStreamSynchronize(s));
+  }
   TD_TRY(td_timestep_sincos_launch(f->tvals, n, f->tproj, s));
   TD_TRY(gemm(f, s, f->tproj, 256, f->t1_w, f->t1_b, f->tmid, D, n, D, 256, TD_ACT_SILU));
   TD_TRY(gemm(f, s, f->tmid, D, f->t2_w, f->t2_b, f->te, D, n, D, D));

@@ -371,7 +371,7 @@ int splitk_workspace(hipStream_t stream, char** out) {
 template <int MB, int NR, bool DEEP>
 int launch_one(const TdGemmParams& p, dim3 grid, char* ws, hipStream_t stream) {
   constexpr int lds = gemv_lds_bytes<MB, NR>();
-  if (lds > 64 * 1024) {        // beyond the default dynamic-LDS limit: raise it once per device
+  if (lds + 64 >= 64 * 1024) {  // dynamic + the static ticket word reach the default 64 KiB limit: raise it once per device
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
     TD_CHECK_HIP(hipGetDevice(&dev));

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(NT) void td_sample_top_p_kernel(const bf16_t* __res
   for (int i = 1; i < NW; ++i) kmax = max(kmax, s_red[i]);
   __syncthreads();
 
-  if (!(temperature > 0.f)) {
+  // A +inf logit has all the mass (every finite logit weighs exp(-inf) = 0 and inf - inf is NaN): that IS the greedy answer,
+  // so such a row takes the greedy path instead of the mass histograms (which would find no crossing bin).
+  if (!(temperature > 0.f) || kmax == 0xff80u) {
     // greedy: the first index holding the maximum
     unsigned best = 0xffffffffu;
     for (int c = tid; c < nchunk; c += NT) {
@@ -177,6 +179,8 @@ __global__ __launch_bounds__(NT) void td_sample_top_p_kernel(const bf16_t* __res
   }
   u64 target = top_p >= 1.0f ? Z : (u64)((double)top_p * (double)Z);
   target = target < 1ull ? 1ull : (target > Z ? Z : target);
+  if (tid == 0) { s_bin = 255; s_above = 0ull; }      // defined whatever the masses are (find_crossing writes only where it finds the bin)
+  __syncthreads();
   find_crossing(bins, 0ull, target, scr64, &s_bin, &s_above);
   const int b_hi = s_bin;
   const u64 above_hi = s_above;
@@ -204,10 +208,13 @@ __global__ __launch_bounds__(NT) void td_sample_top_p_kernel(const bf16_t* __res
     cbins[tid] = n;
   }
   __syncthreads();
+  if (tid == 0) { s_bin = 255; s_above = above_hi; }
+  __syncthreads();
   find_crossing(bins, above_hi, target, scr64, &s_bin, &s_above);
   const unsigned tau = ((unsigned)b_hi << 8) | (unsigned)s_bin;
   const u64 above = s_above;
-  const u64 m_tau = mass_of(tau, xmax, c2);               // > 0: the crossing bin holds mass
+  u64 m_tau = mass_of(tau, xmax, c2);                     // > 0 when the crossing bin holds mass
+  m_tau = m_tau ? m_tau : 1ull;
   const unsigned n_tau = cbins[s_bin];
   u64 k_keep = (target - above + m_tau - 1) / m_tau;       // ties kept: the j-th is kept iff above + j * m_tau < target
   k_keep = k_keep < 1 ? 1 : (k_keep > n_tau ? n_tau : k_keep);
@@ -234,6 +241,8 @@ __global__ __launch_bounds__(NT) void td_sample_top_p_kernel(const bf16_t* __res
   const u64 m_off = block_exclusive_scan<u64>(my_mass, scr64, &mass_total);
   const u64 rnd = splitmix64(splitmix64(seed ^ (0xD1B54A32D192ED03ull * (offset + 1ull))) ^ (0x9E3779B97F4A7C15ull * ((u64)row + 1ull)));
   const u64 r = __umul64hi(rnd, kept);                       // uniform in [0, kept); mass_total == kept by construction
+  if (tid == 0) out[row] = 0;                              // always defined; the owner of r overwrites it below
+  __syncthreads();
   if (my_mass > 0 && r >= m_off && r < m_off + my_mass) {
     u64 run = m_off;
     unsigned ties_seen = 0;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(NT) void td_sample_top_p_kernel(const bf16_t* __res
         run += m;
       }
     }
-    out[row] = pick;
+    if (pick >= 0) out[row] = pick;
   }
 }
 
