@@ -58,6 +58,157 @@ __device__ __forceinline__ float half_swap_sum(float x) {
   return a + b;
 }
 
+// The smallest bf16-representable value >= x: a positive magnitude rounds up, a negative one is truncated.
+__device__ __forceinline__ float bf16_ceil(float x) {
+  const unsigned u = as_u32(x);
+  return as_f32((u & 0x80000000u) ? (u & 0xffff0000u) : ((u + 0xffffu) & 0xffff0000u));
+}
+
+// ---- the tile body shared by the two kernels -------------------------------------------------------------------------------
+// Round 3: the softmax's per-score VALU work that is NOT the exponential moved onto the matrix pipe (rocprofv3 SQ counters of
+// round 2: 6.0 VALU per MFMA, the SIMD's issue slots -- not the half-busy matrix pipe -- set the pace):
+//  * the running reference m of a query row enters the scores INSIDE the QK^T accumulation: one extra k-step whose K-side
+//    fragment is the constant column 1 and whose Q-side fragment holds -m (m is kept bf16-representable, so the product is exact;
+//    softmax is invariant to the reference point, any m serves) -- the accumulator leaves the MFMA chain as s - m and the
+//    per-score `fma(s, c, -m c)` disappears (32 per tile and lane), with q pre-multiplied by scale * log2(e) where its producer
+//    rounds it to bf16 anyway (TdAttnParams::q_prescaled; otherwise one multiply per score remains);
+//  * the row sums come from the P.V product itself: one more output row-block whose V^T rows are all ones (4 MFMAs per tile
+//    into a 16-register accumulator, every register the complete sum over the 64 keys) replaces 32 adds per tile and lane and
+//    the half swap at the end; the sum is over the bf16-rounded probabilities the P.V product consumes.
+// Per 64-key tile and wave: 38 MFMAs (was 32) against ~32 v_exp + 16 v_cvt_pk + 16 v_max3 (+ rare rescales).
+template <unsigned PO>
+__device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8_t (&qf)[8], const bf16x8_t kone, const bf16x8_t qnegm,
+                                                 const unsigned (&ka)[8]) {
+  // K fragments are fetched KPF MFMAs ahead of their use (pinned: hipcc would issue each read right before its consumer and
+  // expose the LDS latency 16 times per tile); depth re-measured in-process at S = 4289: 2 beats 4 and 6 by 2 % (1 ties)
+  constexpr int KPF = 2;
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto kread = [&](int e) {   // e = kb * 8 + ks
+    return *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e & 7] + PO + (e >> 3) * 32 * 256);
+  };
+  bf16x8_t kf[16];
+#pragma unroll
+  for (int e = 0; e < KPF; ++e) kf[e] = kread(e);
+  __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if ((e & 7) == 0) {      // the reference point first: st = 1 . (-m)
+      st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qnegm, zero16, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
+    st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], st[e >> 3], 0, 0, 0);
+    if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  }
+}
+
+// st holds s - m_run (raw score units; log2 units when PRE).  `first`: the first tile of this (part of an) item -- o, lacc are
+// zero and m_run is 0: the reference point is set to the tile's row maximum whatever it is.
+template <unsigned PO, bool PRE>
+__device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t (&o)[4], f32x16_t& lacc, float& m_run, bf16x8_t& qnegm,
+                                                     const bool first, const float c, const unsigned (&va)[2][4], const int h5) {
+  const float cc = PRE ? 1.0f : c;
+  float mx = st[0][0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = max3(mx, st[0][r], st[1][r]);
+  mx = half_swap_max(mx);
+  constexpr float RESCALE_LOG2 = 8.0f;        // deferred rescale: probabilities may reach 2^8 before the reference moves
+  if (first || __any(mx * cc > RESCALE_LOG2)) {
+    float target = first ? mx : fmaxf(mx, 0.f);             // new reference relative to the old one
+    if (!(target > -INFINITY)) target = 0.f;                  // a fully masked row keeps its reference
+    const float m_new = bf16_ceil(m_run + target);
+    const float d = m_new - m_run;                            // exact: both are short bf16 values
+    if (!first) {
+      const float alpha = __builtin_amdgcn_exp2f(-d * cc);
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] -= d;
+    m_run = m_new;
+    qnegm[0] = h5 == 0 ? (short)f2bf(-m_new) : (short)0;
+  }
+  bf16x8_t pf[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4_t pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x0 = st[kb][8 * s + 2 * j], x1 = st[kb][8 * s + 2 * j + 1];
+        const float p0 = __builtin_amdgcn_exp2f(PRE ? x0 : x0 * c);
+        const float p1 = __builtin_amdgcn_exp2f(PRE ? x1 : x1 * c);
+        pk[j] = pack_bf2(p0, p1);
+      }
+      pf[kb][s] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+  }
+
+  // ---- O^T += V^T . P^T, and the row sums as one more row-block of ones ---------------------------------------------------
+  constexpr int VPF = 2;   // V^T fragments in flight ahead of their MFMA (2 transposed reads each)
+  const bf16x8_t ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  auto vread = [&](int e, int jj) {   // e = (kb * 2 + s) * 4 + db
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(uintptr_t)(va[jj][e & 3] + PO + (e >> 2) * 16 * 256));
+  };
+  bf16x4_t v0[16], v1[16];
+#pragma unroll
+  for (int e = 0; e < VPF; ++e) { v0[e] = vread(e, 0); v1[e] = vread(e, 1); }
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * VPF, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e + VPF < 16) { v0[e + VPF] = vread(e + VPF, 0); v1[e + VPF] = vread(e + VPF, 1); }
+    bf16x8_t vf;
+    vf[0] = v0[e][0]; vf[1] = v0[e][1]; vf[2] = v0[e][2]; vf[3] = v0[e][3];
+    vf[4] = v1[e][0]; vf[5] = v1[e][1]; vf[6] = v1[e][2]; vf[7] = v1[e][3];
+    o[e & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[e >> 3][(e >> 2) & 1], o[e & 3], 0, 0, 0);
+    if (e + VPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if ((e & 3) == 3) {
+      lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[e >> 3][(e >> 2) & 1], lacc, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  }
+}
+
+// Normalise and store one wave's 32 x 128 output tile.  A lane holds O[q][db*32 + 8 g + 4 h5 + (0..3)] for g = 0..3: with the two
+// lane halves of a row exchanged pairwise (v_permlane32_swap: upper half of group g <-> lower half of group g+1) every lane owns 8
+// contiguous columns = one 16-byte store, 8 per lane instead of 16 of 8 bytes: the store tail of an attention workgroup is bound
+// by the number of store instructions, not by bytes (guide, T21).
+// `live`: the lane's row exists (rows past Sq take part in the lane exchange -- the swap needs both halves -- and skip the store).
+__device__ __forceinline__ void attn_store_rows(const f32x16_t (&o)[4], const float inv, bf16_t* row_ptr, const int h5, const bool wide, const bool live) {
+  if (wide) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        unsigned a0 = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv), a1 = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        unsigned b0 = pack_bf2(o[db][4 * g + 4] * inv, o[db][4 * g + 5] * inv), b1 = pack_bf2(o[db][4 * g + 6] * inv, o[db][4 * g + 7] * inv);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+        if (live) *(u32x4_t*)(row_ptr + db * 32 + 8 * (g + h5)) = w;
+      }
+  } else {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        if (live) *(u32x2_t*)(row_ptr + 4 * h5 + db * 32 + 8 * g) = w;
+      }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -67,7 +218,7 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 // accumulator zeroing.  Here every per-lane LDS address lives in a register for the whole kernel (8 for the K row reads,
 // 8 for the V transposed reads; k-block / k-step / tile-slot parts are instruction immediates).
 // ---------------------------------------------------------------------------------------------
-template <bool CAUSAL, int NWAVES, bool BIAS = false, bool VARLEN = false>
+template <bool CAUSAL, int NWAVES, bool BIAS = false, bool VARLEN = false, bool PRE = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(const TdAttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1]
@@ -175,11 +326,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -1e30f;
-  float l_run = 0.f;
+  if ((p.variant & 0x100) && wid >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (A/B switch)
+  f32x16_t lacc;                      // row sums: every register holds the whole sum of its lane's query row
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  float m_run = 0.f;                  // reference point of the row's exponentials (bf16-representable; set by the first tile)
+  const bf16x8_t kone = {(short)(h5 == 0 ? 0x3F80 : 0), 0, 0, 0, 0, 0, 0, 0};   // K-side fragment of the reference k-step: column 0 = 1
+  bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};                                       // Q-side: row 0 = -m_run
   const float c = p.scale * 1.4426950408889634f;
   const int q_pos = q0 + l31 + c_off;
-  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // The tile body is instantiated for both double-buffer slots: the slot offset of every LDS read is then an instruction
   // immediate instead of 16 address flips (v_xor) per tile and wave.
@@ -188,27 +343,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     __syncthreads();  // vmcnt(0) + barrier: tile t landed; slot (t+1)&1 no longer read
     if (t + 1 < nt) stage((t + 1) & 1, t + 1);
 
-    // ---- S^T = K . Q^T ------------------------------------------------------------------------
-    // K fragments are fetched KPF MFMAs ahead of their use (pinned: hipcc would issue each read right
-    // before its consumer and expose the LDS latency 16 times per tile)
     f32x16_t st[2];
-    {
-      constexpr int KPF = 2;   // depth re-measured in-process at S = 4289: 2 / 2 beats 4 / 3 and 6 / 5 by 2 % (1 / 1 ties)
-      auto kread = [&](int e) {   // e = kb * 8 + ks
-        return *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e & 7] + PO + (e >> 3) * 32 * 256);
-      };
-      bf16x8_t kf[16];
-#pragma unroll
-      for (int e = 0; e < KPF; ++e) kf[e] = kread(e);
-      __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
-        st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], (e & 7) == 0 ? zero16 : st[e >> 3], 0, 0, 0);
-        if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-    }
+    attn_tile_scores<PO>(st, qf, kone, qnegm, ka);      // S^T - m = K . Q^T - 1 . m
 
     const int key0 = t * KV_TILE;
     if constexpr (BIAS) {   // additive score bias in the scaled domain: (s + bias/scale) * scale = s*scale + bias
@@ -238,64 +374,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
         }
     }
 
-    // ---- online softmax with deferred rescale -----------------------------------------------------
-    float mx = st[0][0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = max3(mx, st[0][r], st[1][r]);
-    mx = half_swap_max(mx);
-    constexpr float RESCALE_LOG2 = 8.0f;
-    if (__any((mx - m_run) * c > RESCALE_LOG2)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    const float mc = m_run * c;
-    float psum = 0.f;
-    bf16x8_t pf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        u32x4_t pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s + 2 * j] * c - mc);
-          const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s + 2 * j + 1] * c - mc);
-          psum += p0 + p1;
-          pk[j] = pack_bf2(p0, p1);
-        }
-        pf[kb][s] = __builtin_bit_cast(bf16x8_t, pk);
-      }
-    }
-    l_run += psum;
-
-    // ---- O^T += V^T . P^T ------------------------------------------------------------------------
-    {
-      constexpr int VPF = 2;   // V^T fragments in flight ahead of their MFMA (2 transposed reads each)
-      auto vread = [&](int e, int jj) {   // e = (kb * 2 + s) * 4 + db
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(uintptr_t)(va[jj][e & 3] + PO + (e >> 2) * 16 * 256));
-      };
-      bf16x4_t v0[16], v1[16];
-#pragma unroll
-      for (int e = 0; e < VPF; ++e) { v0[e] = vread(e, 0); v1[e] = vread(e, 1); }
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * VPF, 0);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        if (e + VPF < 16) { v0[e + VPF] = vread(e + VPF, 0); v1[e + VPF] = vread(e + VPF, 1); }
-        bf16x8_t vf;
-        vf[0] = v0[e][0]; vf[1] = v0[e][1]; vf[2] = v0[e][2]; vf[3] = v0[e][3];
-        vf[4] = v1[e][0]; vf[5] = v1[e][1]; vf[6] = v1[e][2]; vf[7] = v1[e][3];
-        o[e & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[e >> 3][(e >> 2) & 1], o[e & 3], 0, 0, 0);
-        if (e + VPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-    }
-
+    attn_tile_softmax_pv<PO, PRE>(st, o, lacc, m_run, qnegm, t == 0, c, va, h5);
   };
   {
     int t = 0;
@@ -306,21 +385,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     if (t < nt) tile(t, std::integral_constant<unsigned, 0>{});
   }
 
-  const float l_tot = half_swap_sum(l_run);
-  const float inv = 1.0f / l_tot;
+  const float inv = 1.0f / lacc[0];
   const int q = q0 + l31;
-  if (q < Sq) {
-    bf16_t* op = Ob + (size_t)q * p.ldo + head * D + 4 * h5;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2_t w;
-        w[0] = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-        w[1] = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-        *(u32x2_t*)(op + db * 32 + 8 * g) = w;
-      }
-  }
+  attn_store_rows(o, inv, Ob + (size_t)min(q, Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < Sq);
 #endif
 }
 
@@ -355,7 +422,7 @@ constexpr int SK_MAX_RANGES = SK_HEADER_BYTES / 4 - 16;
 // workspace = [header | T slots: ranges x SK_SLOT_FLOATS | H slots: ranges x SK_SLOT_FLOATS]
 }  // namespace
 
-template <int NWAVES, bool XCD_REMAP>
+template <int NWAVES, bool XCD_REMAP, bool PRE = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kernel(const TdAttnParams p, char* __restrict__ ws,
                                                                                   const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -385,7 +452,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
   constexpr int SG = (GROUPS + NWAVES - 1) / NWAVES;
   const int srow = lane >> 4;
   const float c = p.scale * 1.4426950408889634f;
-  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float cc = PRE ? 1.0f : c;          // scale of the stored reference points: log2 units when q arrives pre-scaled
+  const bf16x8_t kone = {(short)(h5 == 0 ? 0x3F80 : 0), 0, 0, 0, 0, 0, 0, 0};   // K-side fragment of the reference k-step (attn_tile_scores)
 
   // ---- resident per-lane LDS byte addresses of slot 0 (the other slot is an immediate offset in the tile body) ----
   const unsigned lds0 = (unsigned)(uintptr_t)(TD_LDS char*)smem;
@@ -408,6 +476,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     }
   }
 
+  if ((p.variant & 0x100) && wid >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (A/B switch)
   while (it < it_end) {
     // ---- the part of an item this workgroup runs now: KV tiles [kb, ke) of item `item` -------------------------------
     const int item = (int)(it / nt);
@@ -467,8 +536,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) o[db][rr] = 0.f;
-    float m_run = -1e30f;
-    float l_run = 0.f;
+    f32x16_t lacc;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) lacc[rr] = 0.f;
+    float m_run = 0.f;
+    bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};
 
     auto tile = [&](const int t, auto slot_tag) {
       constexpr unsigned SLOT = decltype(slot_tag)::value;
@@ -477,23 +549,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       if (t + 1 < ke) stage(SLOT ^ 1, t + 1);
 
       f32x16_t st[2];
-      {
-        constexpr int KPF = 2;
-        auto kread = [&](int e) {   // e = kb * 8 + ks
-          return *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e & 7] + PO + (e >> 3) * 32 * 256);
-        };
-        bf16x8_t kf[16];
-#pragma unroll
-        for (int e = 0; e < KPF; ++e) kf[e] = kread(e);
-        __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
-          st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], (e & 7) == 0 ? zero16 : st[e >> 3], 0, 0, 0);
-          if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-      }
+      attn_tile_scores<PO>(st, qf, kone, qnegm, ka);
 
       const int key0 = t * KV_TILE;
       if (key0 + KV_TILE > Skv) {        // last tile: keys >= Skv are masked
@@ -506,61 +562,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
           }
       }
 
-      float mx = st[0][0];
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) mx = max3(mx, st[0][rr], st[1][rr]);
-      mx = half_swap_max(mx);
-      constexpr float RESCALE_LOG2 = 8.0f;
-      if (__any((mx - m_run) * c > RESCALE_LOG2)) {
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) o[db][rr] *= alpha;
-      }
-      const float mc = m_run * c;
-      float psum = 0.f;
-      bf16x8_t pf[2][2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          u32x4_t pk;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float p0 = __builtin_amdgcn_exp2f(st[kk][8 * s2 + 2 * j] * c - mc);
-            const float p1 = __builtin_amdgcn_exp2f(st[kk][8 * s2 + 2 * j + 1] * c - mc);
-            psum += p0 + p1;
-            pk[j] = pack_bf2(p0, p1);
-          }
-          pf[kk][s2] = __builtin_bit_cast(bf16x8_t, pk);
-        }
-      }
-      l_run += psum;
-
-      {
-        constexpr int VPF = 2;
-        auto vread = [&](int e, int jj) {   // e = (kb * 2 + s) * 4 + db
-          return __builtin_amdgcn_ds_read_tr16_b64_v4i16((TD_LDS bf16x4_t*)(uintptr_t)(va[jj][e & 3] + PO + (e >> 2) * 16 * 256));
-        };
-        bf16x4_t v0[16], v1[16];
-#pragma unroll
-        for (int e = 0; e < VPF; ++e) { v0[e] = vread(e, 0); v1[e] = vread(e, 1); }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * VPF, 0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          if (e + VPF < 16) { v0[e + VPF] = vread(e + VPF, 0); v1[e + VPF] = vread(e + VPF, 1); }
-          bf16x8_t vf;
-          vf[0] = v0[e][0]; vf[1] = v0[e][1]; vf[2] = v0[e][2]; vf[3] = v0[e][3];
-          vf[4] = v1[e][0]; vf[5] = v1[e][1]; vf[6] = v1[e][2]; vf[7] = v1[e][3];
-          o[e & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[e >> 3][(e >> 2) & 1], o[e & 3], 0, 0, 0);
-          if (e + VPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-      }
+      attn_tile_softmax_pv<PO, PRE>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5);
     };
     {
       int t = kb;
@@ -570,6 +572,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       }
       if (t < ke) tile(t, std::integral_constant<unsigned, 0>{});
     }
+    float l_run = lacc[0];           // the complete row sum (every register of lacc holds it, in both lane halves)
     // ---- what happens to the state: leave it for the other owner, combine with the other owner's, or just finish ----------
     if (kb > 0 || ke < nt) {
       const int j = kb > 0 ? r : r + 1;                  // boundary between ranges j-1 (head part) and j (tail part)
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       const u32x4_t ml = __builtin_amdgcn_raw_buffer_load_b128(rsS, theirs + 16 * 1024u, 0, 0);
       const float m2 = as_f32(ml[0]), l2 = as_f32(ml[1]);
       const float mm = fmaxf(m_run, m2);
-      const float a1 = __builtin_amdgcn_exp2f((m_run - mm) * c), a2 = __builtin_amdgcn_exp2f((m2 - mm) * c);
+      const float a1 = __builtin_amdgcn_exp2f((m_run - mm) * cc), a2 = __builtin_amdgcn_exp2f((m2 - mm) * cc);
       // One operation order whoever merges -- fma(head, a_head, tail * a_tail) -- so the result does not depend on which owner
       // arrived second (it does under load; the sum is otherwise the same to one fp32 rounding).
       auto comb = [&](float own, float other) {
@@ -627,21 +630,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     }
 
     // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] ------------------------------------------
-    const float l_tot = half_swap_sum(l_run);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / l_run;
     const int q = q0 + l31;
-    if (q < p.Sq) {
-      bf16_t* op = p.O + (size_t)batch * p.o_bstride + (size_t)q * p.ldo + head * D + 4 * h5;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2_t w;
-          w[0] = pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-          w[1] = pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-          *(u32x2_t*)(op + db * 32 + 8 * g) = w;
-        }
-    }
+    attn_store_rows(o, inv, p.O + (size_t)batch * p.o_bstride + (size_t)min(q, p.Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < p.Sq);
   }
 #endif
 }
@@ -702,7 +693,7 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
                "td_attention: per-batch operand exceeds the 4 GiB buffer-descriptor range");
   TD_CHECK_ARG(((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0, "td_attention: pointers must be 16-byte aligned");
   // one query token per sequence against its KV cache: the dedicated decode kernel (keys split over lanes, GQA group shares K/V)
-  if (p.Sq == 1 && p.causal && !p.bias && p.variant == 0 && (p.kv_lens || p.causal_offset == p.Skv - 1))
+  if (p.Sq == 1 && p.causal && !p.bias && (p.variant & 0xff) == 0 && (p.kv_lens || p.causal_offset == p.Skv - 1))
     return td_attn_decode_launch(p, stream);
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
@@ -717,6 +708,7 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   dim3 grid((p.Sq + NW * Q_WAVE - 1) / (NW * Q_WAVE), p.Hq, p.batch);
   if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
   if (p.kv_lens) TD_CHECK_ARG(p.causal && !p.bias, "td_attention: per-sequence kv lengths exist for the causal kernel only");
+  if (p.q_prescaled) TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts, "td_attention: pre-scaled q is a form of the joint (unmasked) attention only");
   if (p.seg_starts) {   // packed segments: plain grid over (query tiles of the longest segment, heads, segments)
     TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && p.Sq == p.Skv, "td_attention(varlen): full attention inside each segment only (no mask, bias or cache lengths)");
     static std::atomic<unsigned long long> a6{0};
@@ -731,13 +723,17 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   const int n_items = (int)(grid.x * grid.y * grid.z);
   const int cus = device_cus(dev);
   const int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
-  if (!p.causal && !p.bias && !p.kv_lens && p.variant != 1 && cus > 0 && n_items > cus && cus < SK_MAX_RANGES && (long long)n_items * nt < (1ll << 31)) {
+  if (!p.causal && !p.bias && !p.kv_lens && (p.variant & 0xff) != 1 && cus > 0 && n_items > cus && cus < SK_MAX_RANGES && (long long)n_items * nt < (1ll << 31)) {
     char* ws = (char*)p.sk_ws;
     if (!ws) {
       if (int rc = sk_pooled_workspace(dev, cus, stream, &ws)) return rc;
     }
     constexpr int lds_sk = lds + 16;        // + the ticket word
-    if (p.variant == 2) {
+    if (p.q_prescaled) {
+      static std::atomic<unsigned long long> a7{0};
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true, true>, lds_sk, a7, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
+    } else if ((p.variant & 0xff) == 2) {
       if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, false>, lds_sk, a4, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, false>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
     } else {
@@ -756,7 +752,11 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
     }
   } else {
-    if (p.causal) {
+    if (p.q_prescaled) {
+      static std::atomic<unsigned long long> a8{0};
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, false, true>, lds, a8, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, false, true>), grid, dim3(NW * 64), lds, stream, q);
+    } else if (p.causal) {
       if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<true, NW>, lds, a2, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW>), grid, dim3(NW * 64), lds, stream, q);
     } else {

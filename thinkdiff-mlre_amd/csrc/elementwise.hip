@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256) void td_qk_norm_rope_kernel(const TdQkRopePara
         y[i + 1] = x[i + 1] * cs[i + 1] + x[i] * sn[i + 1];
       }
     }
+    if (!is_k && p.q_premul != 1.0f) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] *= p.q_premul;
+    }
     *(u32x4_t*)hp = pack8(y);
   }
 }

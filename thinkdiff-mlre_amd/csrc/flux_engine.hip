@@ -618,9 +618,12 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   TdQkRopeParams rp;
   rp.qkv = f->qkv; rp.ld = 3 * D; rp.rows = S; rp.Hq = H; rp.Hk = H; rp.q_col = 0; rp.k_col = D;
   rp.cos = f->cosT; rp.sin = f->sinT; rp.split = T; rp.eps = 1e-6f;
+  rp.q_premul = scale * 1.4426950408889634f;      // q leaves RoPE in the exp2 domain of the attention kernel (one bf16 rounding, as before)
   TdAttnParams ap;
   ap.Q = f->qkv; ap.K = f->qkv + D; ap.V = f->qkv + 2 * D; ap.ldq = ap.ldkv = 3 * D;
-  ap.Sq = ap.Skv = S; ap.Hq = ap.Hkv = H; ap.scale = scale; ap.batch = 1; ap.sk_ws = f->attn_ws; ap.variant = f->attn_variant;
+  static const int attn_tune = getenv("TD_ATTN_TUNE") ? (int)strtol(getenv("TD_ATTN_TUNE"), nullptr, 0) & ~0xff : 0;   // A/B switches of the attention kernel (experiments)
+  ap.Sq = ap.Skv = S; ap.Hq = ap.Hkv = H; ap.scale = scale; ap.batch = 1; ap.sk_ws = f->attn_ws; ap.variant = f->attn_variant | attn_tune;
+  ap.q_prescaled = 1;
 
   // fp8 mode: the LayerNorm-modulate kernel emits e4m3 rows + per-token scales directly; attention / MLP outputs
   // get a per-token quantisation pass; every block GEMM then runs on the fp8 MFMA path.

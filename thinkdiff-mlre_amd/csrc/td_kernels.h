@@ -68,6 +68,9 @@ struct TdAttnParams {
   // optional hand-off workspace of the persistent (stream-K) joint-attention kernel: td_attn_streamk_ws_bytes() bytes, zeroed
   // once by its owner, not shared by launches that may run concurrently (null: a per-(device, stream) one is created inside)
   void* sk_ws = nullptr;
+  // q already carries scale * log2(e) (folded in where q was last rounded to bf16: TdQkRopeParams::q_premul), so scores arrive in
+  // the exp2 domain and `scale` is not applied again; joint (non-causal, no bias / lengths / segments) attention only
+  int q_prescaled = 0;
 };
 size_t td_attn_streamk_ws_bytes();
 
@@ -102,6 +105,9 @@ struct TdQkRopeParams {
   const bf16_t* wqB = nullptr; const bf16_t* wkB = nullptr;
   float eps = 1e-6f;
   int rotate_half = 0;  // 0: interleaved pairs (FLUX), 1: half-split fp32, 2: half-split with bf16 op rounding (Qwen2)
+  // q (not k) is multiplied by this in fp32 before its one rounding to bf16: the attention scale * log2(e), so that the attention
+  // kernel needs no per-score multiply (TdAttnParams::q_prescaled).  1 = the plain reference values.
+  float q_premul = 1.0f;
 };
 int td_qk_norm_rope_launch(const TdQkRopeParams& p, hipStream_t stream);
 
