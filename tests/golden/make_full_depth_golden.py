@@ -57,7 +57,7 @@ def main(jobs):
         fx = {"job": job, "T": spec["T"], "seed": spec["seed"], "weight_seed": C.WEIGHT_SEED, "weights_checksum": ck, "vae_checksum": vck,
               "steps": list(C.GOLDEN_STEPS), "latents": torch.stack([trace[s - 1][0] for s in C.GOLDEN_STEPS]).contiguous(),
               "image_u8": u8[0].contiguous(), "oracle_seconds": time.time() - t0, "oracle_threads": torch.get_num_threads(),
-              "torch": torch.__version__}
+              "torch": str(torch.__version__)}
         torch.save(fx, os.path.join(HERE, f"full_depth_{job}.pt"))
         print(f"{job}: written ({fx['oracle_seconds']:.0f} s)", flush=True)
 

@@ -52,8 +52,8 @@ def test_mixed_device_and_short_arguments_are_rejected(hip):
         kw.update(bad)
         with pytest.raises(RuntimeError):
             O.linear(x, w, kw["bias"], 0, kw["gate"], kw["res"])
-    w0, w2 = torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda"), torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda")
-    v = torch.zeros(256, dtype=torch.bfloat16, device="cuda")
+    w0, w2 = torch.zeros(512, 256, dtype=torch.bfloat16, device="cuda"), torch.zeros(512, 512, dtype=torch.bfloat16, device="cuda")
+    v = torch.zeros(512, dtype=torch.bfloat16, device="cuda")                # hidden = 512 (the T5-RMSNorm kernel takes multiples of 512)
     O.aligner_mlp2x(x, w0, v, w2, v, v, 1e-6, False)                      # well-formed call passes
     for args in ((x, w0, v.cpu(), w2, v, v), (x, w0, v, w2, v[:128], v), (x, w0, v, w2, v, v.float()), (x, w0[:128], v, w2, v, v),
                  (x, w0, v, w2[:, :128].contiguous(), v, v)):
@@ -67,4 +67,4 @@ def test_mixed_device_and_short_arguments_are_rejected(hip):
     with pytest.raises(RuntimeError):
         O.attention(q, q.repeat(2, 1, 1), q.repeat(2, 1, 1), 2, 2, 0.088, False)   # k/v batch differs from q's
     with pytest.raises(RuntimeError):
-        O.norm_rows(x.repeat(1, 2).contiguous(), False, 1e-6, None, 0, v.cpu().repeat(2), v.repeat(2), None, None)
+        O.norm_rows(x.repeat(1, 2).contiguous(), False, 1e-6, None, 0, v.cpu(), v, None, None)

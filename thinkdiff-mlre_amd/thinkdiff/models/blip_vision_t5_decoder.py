@@ -14,8 +14,10 @@ from types import SimpleNamespace
 import torch
 
 from .. import _hip
+from ..ops import register as _register_ops
 from ..common.registry import registry
 from .base_model import BaseModel
+_OPS = _register_ops()      # torch.ops.thinkdiff_hip: the custom-op layer over the C ABI (GPU kernels only, no fallback)
 
 
 class IdentityMap:
@@ -55,8 +57,8 @@ class HipVisionProjector:
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.mm_hidden_size).to(torch.bfloat16).contiguous()
         p = self.params
-        y = _hip.aligner_mlp2x(x2, p["0.weight"], p["0.bias"], p["2.weight"], p["2.bias"], p["3.weight"],
-                               eps=1e-6, fp32_norm=self.fp32_norm)
+        # the aligner runs as a PyTorch custom op (thinkdiff/ops.py: TORCH_LIBRARY over td_aligner_mlp2x_bf16; GPU kernel only)
+        y = _OPS.aligner_mlp2x(x2, p["0.weight"], p["0.bias"], p["2.weight"], p["2.bias"], p["3.weight"], 1e-6, bool(self.fp32_norm))
         return y.reshape(*lead, self.hidden_size)
 
 
@@ -120,5 +122,5 @@ class BlipVisionT5DecoderForConditionalGeneration(BaseModel):
         if self.config.vision_downsample_factor is not None:
             if self.config.vision_downsample_factor != 2:
                 raise _hip.ThinkDiffHipError("vision_downsample_factor: only 2 (all shipped configs) has a HIP path")
-            x = torch.stack([_hip.cls_avgpool2(x[b].contiguous()) for b in range(x.shape[0])])
+            x = torch.stack([_OPS.cls_avgpool2(x[b].contiguous()) for b in range(x.shape[0])])
         return self.mm_projector(x)

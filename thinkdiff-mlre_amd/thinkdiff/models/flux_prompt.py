@@ -18,7 +18,9 @@ import numpy as np
 import torch
 
 from .. import _hip
+from ..ops import register as _register_ops
 from .flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+_OPS = _register_ops()      # torch.ops.thinkdiff_hip: the custom-op layer over the C ABI (GPU kernels only, no fallback)
 
 
 class FlowMatchEulerSchedule:
@@ -164,7 +166,7 @@ class FluxPipelineRewritePrompt:
             # the engine updates latents in place; diffusers never mutates the caller's tensor, so work on a copy
             return latents.to(dev, torch.bfloat16).contiguous().clone(), h, w
         raw = torch.randn((batch, c, h, w), generator=generator, device=dev, dtype=torch.bfloat16)
-        packed = torch.stack([_hip.flux_pack_latents(raw[b]) for b in range(batch)])
+        packed = torch.stack([_OPS.flux_pack_latents(raw[b]) for b in range(batch)])
         return packed, h, w
 
     # ---- the call the drivers make --------------------------------------------------------------------------
@@ -223,7 +225,7 @@ class FluxPipelineRewritePrompt:
             if output_type == "latent":      # diffusers: packed latents, no unpack
                 outs.append(x)
             elif output_type == "vae_input":  # _unpack_latents + (z / scaling_factor + shift_factor), no decode
-                outs.append(_hip.flux_unpack_latents(x, tr.config.in_channels // 4, h, w,
+                outs.append(_OPS.flux_unpack_latents(x, tr.config.in_channels // 4, h, w,
                                                      self.vae_scaling_factor, self.vae_shift_factor))
             elif self.vae is None:
                 raise _hip.ThinkDiffHipError("no VAE loaded: call with output_type='latent' (packed latents) or "

@@ -14,6 +14,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from .. import _hip
+from ..ops import register as _register_ops
+_OPS = _register_ops()      # torch.ops.thinkdiff_hip: the custom-op layer over the C ABI (GPU kernels only, no fallback)
 
 
 @dataclasses.dataclass
@@ -234,7 +236,7 @@ class Qwen2VLTextEngine:
                     break
                 nxt = forced_dev[step:step + 1]
             else:
-                nxt = _hip.sample_top_p(logits, sampling.temperature, sampling.top_p, key, step)     # device int32 [1], no host round trip
+                nxt = _OPS.sample_top_p(logits, float(sampling.temperature), float(sampling.top_p), int(key), int(step))     # device int32 [1], no host round trip
             out_tok.append(nxt)
             # one token against the cache: the decode step (fused rope + cache write, decode attention, gated-MLP weight stream)
             h1, lg = self.decode_batch(nxt, [[next_pos + step]] * 3, [n_p + step])
@@ -321,7 +323,7 @@ class Qwen2VLTextEngine:
                 toks = [int(forced_output_ids[owner[i]][step]) for i in range(n)]
             else:
                 # one launch for all live rows (td_sample_top_p_bf16); the ids come to the host once per step for the bookkeeping below
-                toks = _hip.sample_top_p(logits[:n], sampling.temperature, sampling.top_p, key, step).tolist()
+                toks = _OPS.sample_top_p(logits[:n], float(sampling.temperature), float(sampling.top_p), int(key), int(step)).tolist()
             pos = torch.tensor([[next_pos[i] for i in range(n)]] * 3, dtype=torch.int32)
             hid, logits = self.decode_batch(toks, pos, cache_len[:n])
             keep = []
