@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["auto", "one_wg_per_item", "streamk_no_remap"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 0x400, 0x401], ids=["auto", "one_wg_per_item", "streamk_no_remap", "two_blocks_per_wave", "two_blocks_plain_grid"], autouse=True)
 def all_variants(request, hip):
     """Every kernel structure behind td_attention_bf16 must pass every case."""
     prev = hip.lib().td_attention_set_variant(request.param)
@@ -179,3 +179,31 @@ def test_packed_variable_length_segments(hip):
 def _rel_close(a, b, tol=2.0 ** -7):
     a, b = a.float().cpu(), b.float().cpu()
     return bool((a - b).abs().max() <= tol * b.abs().max())
+
+
+@pytest.mark.parametrize("S,H", [(449, 4), (4289, 24), (4354, 24)])
+def test_prescaled_q_form(hip, S, H):
+    """The form the FLUX engine uses: q arrives multiplied by scale * log2(e) (rounded to bf16 once, where RoPE rounds it), the
+    kernel applies no scale of its own and exponentiates in base 2.  Reference: softmax over ln(2) * q'.k in fp32."""
+    g = torch.Generator().manual_seed(S * 3 + H)
+    qkv = torch.randn(1, S, 3 * H * 128, generator=g).bfloat16()
+    c = (128 ** -0.5) * 1.4426950408889634
+    qkv[:, :, :H * 128] = (qkv[:, :, :H * 128].float() * c).bfloat16()
+    d = qkv.cuda()
+    q, k, v = d[:, :, :H * 128], d[:, :, H * 128:2 * H * 128], d[:, :, 2 * H * 128:]
+    lib = hip.lib()
+    cur = lib.td_attention_set_variant(0)
+    lib.td_attention_set_variant(cur | 0x800)
+    try:
+        out = torch.zeros(1, S, H * 128, dtype=torch.bfloat16, device="cuda")
+        hip.attention(q, k, v, out, H, H)
+        torch.cuda.synchronize()
+    finally:
+        lib.td_attention_set_variant(cur)
+    hs = [0, H - 1] if H > 4 else list(range(H))              # the fp32 reference of 24 heads x 4354^2 is slow: check two heads
+    for h in hs:
+        qh = qkv[0, :, h * 128:(h + 1) * 128].float()
+        kh = qkv[0, :, (H + h) * 128:(H + h + 1) * 128].float()
+        vh = qkv[0, :, (2 * H + h) * 128:(2 * H + h + 1) * 128].float()
+        ref = torch.softmax((qh @ kh.T) * math.log(2.0), dim=-1) @ vh
+        _check(out[0, :, h * 128:(h + 1) * 128], ref)

@@ -90,7 +90,9 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
   p.batch = batch; p.Sq = Sq; p.Skv = Skv; p.Hq = Hq; p.Hkv = Hkv; p.head_dim = head_dim;
   p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo;
   p.q_bstride = q_bstride; p.kv_bstride = kv_bstride; p.o_bstride = o_bstride;
-  p.scale = scale; p.causal = causal; p.causal_offset = Skv - Sq; p.variant = g_attn_variant;
+  p.scale = scale; p.causal = causal; p.causal_offset = Skv - Sq; p.variant = g_attn_variant & ~0x800;
+  // test hook (td_attention_set_variant bit 0x800): q already carries scale * log2(e) -- the form the FLUX engine's RoPE kernel hands over
+  p.q_prescaled = (g_attn_variant & 0x800) && !causal ? 1 : 0;
   return td_attn_launch(p, (hipStream_t)stream);
 }
 
