@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1, 2, 0x400, 0x401], ids=["auto", "one_wg_per_item", "streamk_no_remap", "two_blocks_per_wave", "two_blocks_plain_grid"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "one_wg_per_item", "streamk_no_remap"], autouse=True)
 def all_variants(request, hip):
     """Every kernel structure behind td_attention_bf16 must pass every case."""
     prev = hip.lib().td_attention_set_variant(request.param)

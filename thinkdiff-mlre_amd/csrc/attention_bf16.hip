@@ -500,7 +500,11 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
     return td_attn_decode_launch(p, stream);
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
-  // Structures that lost the in-process A/B on MI355X and were removed: ping-pong wave halves with a 3-deep V ring (-9 %),
+  // Structures that lost the in-process A/B on MI355X and were removed: a 4-wave workgroup with ONE wave per SIMD, each wave
+  // owning two 32-row blocks half a tile apart (softmax of one block on the VALU under the other block's MFMAs, 3-deep K / V
+  // rings, the guide's "512-register" shape; round 3: correct, 448 vs 219 us -- with > 256 live registers hipcc puts every
+  // accumulator AND the Q fragments in AGPRs and moves ~400 values per tile through v_accvgpr_read/write, plus 1 KB of scratch),
+  // ping-pong wave halves with a 3-deep V ring (-9 %),
   // 4-wave workgroups two per CU (-35 %), intra-wave QK^T(t+1) / softmax(t) software pipelining (-6 %), the first
   // lockstep kernel with per-read address arithmetic (-15 %).
   constexpr int NW = 8;
@@ -526,14 +530,6 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   const int n_items = (int)(grid.x * grid.y * grid.z);
   const int cus = device_cus(dev);
   const int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
-  if ((p.variant & 0x400) && !p.causal && !p.bias && !p.kv_lens) {      // A/B switch: the 4-wave two-block kernel
-    const bool persistent = (p.variant & 0xff) != 1 && cus > 0 && n_items > cus && cus < SK_MAX_RANGES && (long long)n_items * nt < (1ll << 31);
-    char* ws = (char*)p.sk_ws;
-    if (persistent && !ws) {
-      if (int rc = sk_pooled_workspace(dev, cus, stream, &ws)) return rc;
-    }
-    return td_attn_pp_launch(q, ws, persistent ? cus : n_items, (int)grid.x, nt, stream);
-  }
   if (!p.causal && !p.bias && !p.kv_lens && (p.variant & 0xff) != 1 && cus > 0 && n_items > cus && cus < SK_MAX_RANGES && (long long)n_items * nt < (1ll << 31)) {
     char* ws = (char*)p.sk_ws;
     if (!ws) {

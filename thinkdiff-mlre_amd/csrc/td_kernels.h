@@ -75,8 +75,6 @@ struct TdAttnParams {
 size_t td_attn_streamk_ws_bytes();
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);
-// the 4-wave, two-row-blocks-per-wave joint-attention kernel (csrc/attention_pp.hip); grid = CUs (stream-K, ws needed) or = items
-int td_attn_pp_launch(const TdAttnParams& q, char* ws, int grid, int n_qblk, int nt, hipStream_t stream);
 // Sq = 1 (KV-cached decode) form, csrc/attention_decode.hip; td_attn_launch routes to it
 int td_attn_decode_launch(const TdAttnParams& p, hipStream_t stream);
 
