@@ -28,6 +28,7 @@ from thinkdiff import tasks  # noqa: E402
 from thinkdiff.common.config import Config  # noqa: E402
 from thinkdiff.common.dist_utils import get_rank, init_distributed_mode  # noqa: E402
 from thinkdiff.models import providers  # noqa: E402
+from thinkdiff.runners import dp_inference as dp  # noqa: E402
 
 
 def list_inputs(folder, suffixes):
@@ -92,7 +93,17 @@ class LvlmEmbedExportDriver:
         os.makedirs(out_dir, exist_ok=True)
         embedding_type = self.cfg.model_cfg.get("embedding_type", "output_embed")
         written = []
-        for url in self.pending(list_inputs(run["image_folder"], self.INPUT_SUFFIXES), out_dir):
+        todo = self.pending(list_inputs(run["image_folder"], self.INPUT_SUFFIXES), out_dir)
+        sharded = bool(run.get("shard_prompts", False))
+        if sharded:
+            # rank 0 plans the pending list (one seed per job, so an embedding does not depend on the world size),
+            # broadcast (RCCL one-to-all), every rank takes jobs[rank::world]; the written paths are gathered on rank 0 in job order.
+            # Default (false) = the reference's replicas: every rank walks the whole folder with seed + rank.
+            todo = dp.shard(dp.broadcast_work_list([(u, run.seed + i) for i, u in enumerate(todo)] if get_rank() == 0 else None))
+        for job in todo:
+            url = job[0] if sharded else job
+            if sharded:
+                setup_seeds(job[1])
             sample, need_process, json_dict = self.request(url)
             with torch.no_grad():
                 lm_in, generated = self.model.get_embed(sample, embedding_type=embedding_type, max_new_tokens=128, need_process=need_process)
@@ -102,6 +113,9 @@ class LvlmEmbedExportDriver:
             paths = save_embed(out_dir, stem(url), lm_in[0], json_dict, generated[0], run["prompt"])
             print(f"Saved embed to {paths[0]}")
             written += paths
+        if sharded:
+            every = dp.gather_results([written])
+            return [p for w in every for p in w] if every is not None else written
         return written
 
 

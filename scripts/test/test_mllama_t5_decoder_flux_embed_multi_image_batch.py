@@ -18,7 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "thinkdiff-mlre_amd"))
 
 from scripts.test.test_mllama_t5_decoder_flux_embed import list_inputs, main as _main, save_embed, stem  # noqa: E402
+from scripts.test.test_mllama_t5_decoder_flux import setup_seeds  # noqa: E402
 from scripts.test.test_mllama_t5_decoder_flux_embed_multi_image import LvlmMultiImageEmbedExportDriver  # noqa: E402
+from thinkdiff.common.dist_utils import get_rank  # noqa: E402
+from thinkdiff.runners import dp_inference as dp  # noqa: E402
 
 
 def batches(urls, batch_size, exists):
@@ -38,6 +41,10 @@ class LvlmMultiImageEmbedBatchExportDriver(LvlmMultiImageEmbedExportDriver):
         os.makedirs(out_dir, exist_ok=True)
         embedding_type = self.cfg.model_cfg.get("embedding_type", "output_embed")
         urls = list_inputs(run["image_folder"], self.INPUT_SUFFIXES)
+        sharded = bool(run.get("shard_prompts", False))
+        if sharded:     # rank 0's task list, broadcast; rank r takes tasks[r::world] and batches its own share
+            urls = dp.shard(dp.broadcast_work_list(urls if get_rank() == 0 else None))
+            setup_seeds(run.seed)                               # the same sampling stream on every rank: a task's text depends on its batch only
         written = []
         for group in batches(urls, run["batch_size"], lambda u: os.path.exists(f"{out_dir}/{stem(u)}.pth")):
             if not group:
@@ -52,6 +59,9 @@ class LvlmMultiImageEmbedBatchExportDriver(LvlmMultiImageEmbedExportDriver):
                 print(f"Saved embed to {paths[0]}")
                 print(f"Saved json to {paths[1]}")
                 written += paths
+        if sharded:
+            every = dp.gather_results([written])
+            return [p for w in every for p in w] if every is not None else written
         return written
 
 

@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "thinkdiff-mlre_amd"))
 from scripts.test.test_mllama_t5_decoder_flux import LvlmFluxDriver, parse_args, setup_seeds  # noqa: E402
 from thinkdiff.common.config import Config  # noqa: E402
 from thinkdiff.common.dist_utils import get_rank, init_distributed_mode  # noqa: E402
+from thinkdiff.runners import dp_inference as dp  # noqa: E402
 
 SYSTEM_PROMPT = "You are a helpful assistant."
 
@@ -83,6 +84,14 @@ class LvlmMultiImageFluxDriver(LvlmFluxDriver):
         out_dir = run["output_dir"]
         os.makedirs(out_dir, exist_ok=True)
         seed = run.seed + get_rank()
+        if run.get("shard_prompts", False):
+            # SURVEY.md 8(e) form of this driver: its work list is ONE request; it is planned on rank 0, broadcast, and taken by
+            # rank 0 (jobs[rank::world]); the other ranks render nothing instead of repeating it under seed + rank
+            work = dp.shard(dp.broadcast_work_list([(0, run.seed)] if get_rank() == 0 else None))
+            if not work:
+                dp.gather_results([])
+                return []
+            seed = work[0][1]
         ckpt_id = os.path.basename(self.cfg.model_cfg["ckpt"] or "")
         question, image_paths, texts, image_names = self.inputs()
         messages = build_messages(question, image_paths, texts, self.QUESTION_IN_CHAT, self.MAX_PIXELS)
@@ -108,6 +117,9 @@ class LvlmMultiImageFluxDriver(LvlmFluxDriver):
                 image.save(path, format="PNG", compress_level=1)
                 print(f"Saved image to {path}")
                 written.append(path)
+        if run.get("shard_prompts", False):
+            every = dp.gather_results(written)
+            return every if every is not None else written
         return written
 
 

@@ -276,3 +276,60 @@ def test_embed_export_host_logic_matches_reference_literals(tmp_path):
     assert txt.fit_tokens(t, None) is t and txt.fit_tokens(t, 5) is t and txt.fit_tokens(t, 3).shape == (1, 3, 3)
     padded = txt.fit_tokens(t, 8)
     assert padded.shape == (1, 8, 3) and torch.equal(padded[:, :5], t) and torch.count_nonzero(padded[:, 5:]) == 0
+
+
+def _embed_shard_worker(rank, world, port, folder, out_dir, q):
+    """One rank of the embedding-export driver with run.shard_prompts=true (stub model: the 'embedding' is drawn from torch's
+    global generator, i.e. it records the per-job seed the driver set)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scripts.test import test_mllama_t5_decoder_flux_embed as emb
+    from thinkdiff.common.config import Node
+
+    class Model:
+        def get_embed(self, sample, embedding_type, max_new_tokens, need_process):
+            return [torch.rand(2, 4)], [f"text for {os.path.basename(sample['url'])}"]
+
+    drv = object.__new__(emb.LvlmEmbedExportDriver)
+    drv.cfg = type("C", (), {})()
+    drv.cfg.run_cfg = Node({"output_dir": out_dir, "seed": 7, "shard_prompts": True, "image_folder": folder, "prompt": "P"})
+    drv.cfg.model_cfg = Node({"embedding_type": "output_embed"})
+    drv.model, drv.device = Model(), "cpu"
+    drv.request = lambda url: ({"url": url}, True, {"src": os.path.basename(url)})
+    res = drv.run()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        q.put(res)
+
+
+def test_sharded_embed_export_two_ranks(tmp_path):
+    """The LVLM embedding-export drivers under run.shard_prompts=true (missing #6): the pending list is planned on rank
+    0, broadcast, split jobs[rank::world]; every job runs under its own seed, so the files are identical for 1 and 2 ranks, and
+    rank 0 gets all written paths back in job order."""
+    folder = tmp_path / "in"
+    folder.mkdir()
+    for k in range(5):
+        (folder / f"img{k}.png").write_bytes(b"x")
+    (folder / "img3.json").write_text("{}")                      # not an input of this driver
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        out = tmp_path / f"w{world}"
+        q = ctx.Queue()
+        port = 35500 + os.getpid() % 2000 + world
+        procs = [ctx.Process(target=_embed_shard_worker, args=(r, world, port, str(folder), str(out), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[world] = (res, {n: open(out / n, "rb").read() for n in sorted(os.listdir(out))})
+    (res1, files1), (res2, files2) = results[1], results[2]
+    assert len(files1) == 10 and files1 == files2                # 5 x (.pth + .json), byte-identical
+    assert sorted(os.path.basename(p) for p in res1) == sorted(os.path.basename(p) for p in res2) == sorted(files1)

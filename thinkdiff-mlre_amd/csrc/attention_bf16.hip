@@ -27,7 +27,7 @@
 // accumulator zeroing.  Here every per-lane LDS address lives in a register for the whole kernel (8 for the K row reads,
 // 8 for the V transposed reads; k-block / k-step / tile-slot parts are instruction immediates).
 // ---------------------------------------------------------------------------------------------
-template <bool CAUSAL, int NWAVES, bool BIAS = false, bool VARLEN = false, bool PRE = false>
+template <bool CAUSAL, int NWAVES, bool BIAS = false, bool VARLEN = false, bool PRE = false, bool RS = true>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(const TdAttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1]
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
         }
     }
 
-    attn_tile_softmax_pv<PO, PRE>(st, o, lacc, m_run, qnegm, t == 0, c, va, h5);
+    attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == 0, c, va, h5);
   };
   {
     int t = 0;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     if (t < nt) tile(t, std::integral_constant<unsigned, 0>{});
   }
 
-  const float inv = 1.0f / lacc[0];
+  const float inv = 1.0f / (RS ? lacc[0] : half_swap_sum(lacc[0]));
   const int q = q0 + l31;
   attn_store_rows(o, inv, Ob + (size_t)min(q, Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < Sq);
 #endif
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 // workspace (one per engine context / stream: concurrent launches must not share it) is zeroed when it is created.
 // ---------------------------------------------------------------------------------------------
 
-template <int NWAVES, bool XCD_REMAP, bool PRE = false>
+template <int NWAVES, bool XCD_REMAP, bool PRE = false, bool RS = true>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kernel(const TdAttnParams p, char* __restrict__ ws,
                                                                                   const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
           }
       }
 
-      attn_tile_softmax_pv<PO, PRE>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5);
+      attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5);
     };
     {
       int t = kb;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       }
       if (t < ke) tile(t, std::integral_constant<unsigned, 0>{});
     }
-    float l_run = lacc[0];           // the complete row sum (every register of lacc holds it, in both lane halves)
+    float l_run = RS ? lacc[0] : half_swap_sum(lacc[0]);           // the complete row sum (RS: every register of lacc holds it, in both lane halves)
     // ---- what happens to the state: leave it for the other owner, combine with the other owner's, or just finish ----------
     if (kb > 0 || ke < nt) {
       const int j = kb > 0 ? r : r + 1;                  // boundary between ranges j-1 (head part) and j (tail part)

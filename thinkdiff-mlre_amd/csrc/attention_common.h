@@ -89,7 +89,9 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
 
 // st holds s - m_run (raw score units; log2 units when PRE).  `first`: the first tile of this (part of an) item -- o, lacc are
 // zero and m_run is 0: the reference point is set to the tile's row maximum whatever it is.
-template <unsigned PO, bool PRE>
+// RS: row sums on the matrix pipe (lacc); otherwise they are added on the VALU into lacc[0] as HALF sums (the caller adds the
+// two lane halves at the end) -- the A/B of which pipe has room on a given shape.
+template <unsigned PO, bool PRE, bool RS = true>
 __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t (&o)[4], f32x16_t& lacc, float& m_run, bf16x8_t& qnegm,
                                                      const bool first, const float c, const unsigned (&va)[2][4], const int h5) {
   const float cc = PRE ? 1.0f : c;
@@ -109,8 +111,10 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      if constexpr (RS) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+      } else lacc[0] *= alpha;
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -120,6 +124,7 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
     qnegm[0] = h5 == 0 ? (short)f2bf(-m_new) : (short)0;
   }
   bf16x8_t pf[2][2];
+  float psum = 0.f;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -130,11 +135,13 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
         const float x0 = st[kb][8 * s + 2 * j], x1 = st[kb][8 * s + 2 * j + 1];
         const float p0 = __builtin_amdgcn_exp2f(PRE ? x0 : x0 * c);
         const float p1 = __builtin_amdgcn_exp2f(PRE ? x1 : x1 * c);
+        if constexpr (!RS) psum += p0 + p1;
         pk[j] = pack_bf2(p0, p1);
       }
       pf[kb][s] = __builtin_bit_cast(bf16x8_t, pk);
     }
   }
+  if constexpr (!RS) lacc[0] += psum;
 
   // ---- O^T += V^T . P^T, and the row sums as one more row-block of ones ---------------------------------------------------
   constexpr int VPF = 2;   // V^T fragments in flight ahead of their MFMA (2 transposed reads each)
@@ -155,7 +162,7 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
     o[e & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[e >> 3][(e >> 2) & 1], o[e & 3], 0, 0, 0);
     if (e + VPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if ((e & 3) == 3) {
+    if (RS && (e & 3) == 3) {
       lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[e >> 3][(e >> 2) & 1], lacc, 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
