@@ -142,7 +142,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   float m_run = 0.f;                  // reference point of the row's exponentials (bf16-representable; set by the first tile)
   const bf16x8_t kone = {(short)(h5 == 0 ? 0x3F80 : 0), 0, 0, 0, 0, 0, 0, 0};   // K-side fragment of the reference k-step: column 0 = 1
   bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};                                       // Q-side: row 0 = -m_run
-  f32x16_t negm16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (TD_ATTN_REF_IN_C experiment)
   const float c = p.scale * 1.4426950408889634f;
   const int q_pos = q0 + l31 + c_off;
 
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     if (t + 1 < nt) stage((t + 1) & 1, t + 1);
 
     f32x16_t st[2];
-    attn_tile_scores<PO>(st, qf, kone, qnegm, ka, negm16);      // S^T - m = K . Q^T - 1 . m
+    attn_tile_scores<PO>(st, qf, kone, qnegm, ka);      // S^T - m = K . Q^T - 1 . m
 
     const int key0 = t * KV_TILE;
     if constexpr (BIAS) {   // additive score bias in the scaled domain: (s + bias/scale) * scale = s*scale + bias
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
         }
     }
 
-    attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == 0, c, va, h5, negm16);
+    attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == 0, c, va, h5);
   };
   {
     int t = 0;
@@ -345,7 +344,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     for (int rr = 0; rr < 16; ++rr) lacc[rr] = 0.f;
     float m_run = 0.f;
     bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16_t negm16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     auto tile = [&](const int t, auto slot_tag) {
       constexpr unsigned SLOT = decltype(slot_tag)::value;
@@ -354,7 +352,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       if (t + 1 < ke) stage(SLOT ^ 1, t + 1);
 
       f32x16_t st[2];
-      attn_tile_scores<PO>(st, qf, kone, qnegm, ka, negm16);
+      attn_tile_scores<PO>(st, qf, kone, qnegm, ka);
 
       const int key0 = t * KV_TILE;
       if (key0 + KV_TILE > Skv) {        // last tile: keys >= Skv are masked
@@ -367,7 +365,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
           }
       }
 
-      attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5, negm16);
+      attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5);
     };
     {
       int t = kb;

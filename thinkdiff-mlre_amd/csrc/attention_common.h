@@ -10,10 +10,6 @@
 #include "td_common.h"
 #include "td_kernels.h"
 
-#ifndef TD_ATTN_REF_IN_C
-#define TD_ATTN_REF_IN_C 0
-#endif
-
 namespace {
 
 constexpr int D = 128;          // head dim
@@ -66,7 +62,7 @@ __device__ __forceinline__ float bf16_ceil(float x) {
 // Per 64-key tile and wave: 38 MFMAs (was 32) against ~32 v_exp + 16 v_cvt_pk + 16 v_max3 (+ rare rescales).
 template <unsigned PO>
 __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8_t (&qf)[8], const bf16x8_t kone, const bf16x8_t qnegm,
-                                                 const unsigned (&ka)[8], const f32x16_t& negm16) {
+                                                 const unsigned (&ka)[8]) {
   // K fragments are fetched KPF MFMAs ahead of their use (pinned: hipcc would issue each read right before its consumer and
   // expose the LDS latency 16 times per tile); depth re-measured in-process at S = 4289: 2 beats 4 and 6 by 2 % (1 ties)
   constexpr int KPF = 2;
@@ -80,19 +76,12 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
   __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-#if TD_ATTN_REF_IN_C
-    // experiment: the reference point as the C operand of the chain's first MFMA (a resident 16-register tuple of -m, rewritten
-    // only when the reference moves) instead of one more k-step
-    if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
-    st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], (e & 7) == 0 ? negm16 : st[e >> 3], 0, 0, 0);
-#else
     if ((e & 7) == 0) {      // the reference point first: st = 1 . (-m)
       st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qnegm, zero16, 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
     st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], st[e >> 3], 0, 0, 0);
-#endif
     if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
   }
@@ -104,7 +93,7 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
 // two lane halves at the end) -- the A/B of which pipe has room on a given shape.
 template <unsigned PO, bool PRE, bool RS = true>
 __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t (&o)[4], f32x16_t& lacc, float& m_run, bf16x8_t& qnegm,
-                                                     const bool first, const float c, const unsigned (&va)[2][4], const int h5, f32x16_t& negm16) {
+                                                     const bool first, const float c, const unsigned (&va)[2][4], const int h5) {
   const float cc = PRE ? 1.0f : c;
   float mx = st[0][0];
 #pragma unroll
@@ -133,10 +122,6 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
       for (int r = 0; r < 16; ++r) st[kb][r] -= d;
     m_run = m_new;
     qnegm[0] = h5 == 0 ? (short)f2bf(-m_new) : (short)0;
-#if TD_ATTN_REF_IN_C
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm16[r] = -m_new;
-#endif
   }
   bf16x8_t pf[2][2];
   float psum = 0.f;
