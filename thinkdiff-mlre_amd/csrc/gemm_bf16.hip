@@ -429,93 +429,6 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 #pragma unroll
   for (int s = SA; s < NS; ++s) stage_one(s, 0, 1, min(1, nt - 1));
   int wcur = 0;
-  if (p.stagger && wr == 1) {
-    // STAGGER (guide, "two waves that run the same program with one barrier per block"): waves 4-7 -- the SIMD partners of
-    // waves 0-3 -- run their MFMAs half a k-tile late.  They still read every fragment of tile t between barrier t and
-    // barrier t+1 (so the LDS / DMA protocol is untouched), but keep the k-step-1 fragments in registers (+32 VGPRs) and
-    // issue those MFMAs after the NEXT barrier, while they read the k-step-0 fragments of the next tile: the two waves
-    // of a SIMD no longer reach their MFMA bursts, their LDS read bursts and the barrier at the same moment.
-    constexpr int MASK_VMEM = 0x010, MASK_DS_READ = 0x100, MASK_MFMA = 0x008;
-    constexpr int NIT = 2 * WM;
-    constexpr int S_PER_IT = (NS + NIT - 1) / NIT;
-    bf16x8_t ha[WM], hw[WN];
-    for (int t = 0; t < nt; ++t) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
-      __builtin_amdgcn_s_barrier();
-      const char* wb = smem + W_REGION + wcur * W_BYTES + woff;
-      const char* ab = smem + (t & 1) * A_BYTES + aoff;
-      const int kt_a = min(t + 1, nt - 1);
-      const int kt_w = min(t + 2, nt - 1);
-      const int abuf_next = (t + 1) & 1;
-      const int wbuf_next = wcur == 0 ? 2 : wcur - 1;
-      wcur = wcur == 2 ? 0 : wcur + 1;
-      bf16x8_t w0[WN], af[2];
-#pragma unroll
-      for (int j = 0; j < WN; ++j) w0[j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + foff0);
-      af[0] = *(const bf16x8_t*)(ab + foff0);
-      __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, WN + 1, 0);
-      // phase A: k-step 1 of tile t-1 out of registers (nothing to do for the first tile but the staging)
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        int nst = 0;
-#pragma unroll
-        for (int q = 0; q < S_PER_IT; ++q) {
-          const int sidx = i * S_PER_IT + q;
-          if (sidx < NS) { stage_one(sidx, abuf_next, wbuf_next, sidx < SA ? kt_a : kt_w); ++nst; }
-        }
-        if (t > 0) {
-#pragma unroll
-          for (int j = 0; j < WN; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hw[j], ha[i], acc[j][i], 0, 0, 0);
-        }
-        switch (nst) {
-          case 1: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 1, 0); break;
-          case 2: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 2, 0); break;
-          case 3: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 3, 0); break;
-          default: break;
-        }
-        if (t > 0) __builtin_amdgcn_sched_group_barrier(MASK_MFMA, WN, 0);
-      }
-      // phase B: k-step 0 of tile t (A fragments one m-tile ahead), while the k-step-1 fragments of tile t go to ha / hw
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int it = WM + i;
-        const int cur = i & 1;
-        int nst = 0;
-#pragma unroll
-        for (int q = 0; q < S_PER_IT; ++q) {
-          const int sidx = it * S_PER_IT + q;
-          if (sidx < NS) { stage_one(sidx, abuf_next, wbuf_next, sidx < SA ? kt_a : kt_w); ++nst; }
-        }
-        int nreads = 1;
-        if (i + 1 < WM) { af[cur ^ 1] = *(const bf16x8_t*)(ab + (i + 1) * 16 * ROW_BYTES + foff0); ++nreads; }
-        ha[i] = *(const bf16x8_t*)(ab + i * 16 * ROW_BYTES + (foff0 ^ 64));
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          if (j % WM == i) { hw[j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + (foff0 ^ 64)); ++nreads; }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j], af[cur], acc[j][i], 0, 0, 0);
-        switch (nst) {
-          case 1: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 1, 0); break;
-          case 2: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 2, 0); break;
-          case 3: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 3, 0); break;
-          default: break;
-        }
-        switch (nreads) {
-          case 1: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 1, 0); break;
-          case 2: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 2, 0); break;
-          case 3: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 3, 0); break;
-          case 4: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 4, 0); break;
-          default: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 5, 0); break;
-        }
-        __builtin_amdgcn_sched_group_barrier(MASK_MFMA, WN, 0);
-      }
-    }
-    // tail: k-step 1 of the last tile
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int j = 0; j < WN; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hw[j], ha[i], acc[j][i], 0, 0, 0);
-  } else
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -665,10 +578,7 @@ int td_gemm_config_id(int M, int N, int K) {
   return t0 < 96 ? 1 : 0;
 }
 
-int td_gemm_launch(const TdGemmParams& p0, hipStream_t stream) {
-  static const int stagger_env = getenv("TD_GEMM_STAGGER") ? atoi(getenv("TD_GEMM_STAGGER")) : -1;    // A/B switch (experiments)
-  TdGemmParams p = p0;
-  if (stagger_env >= 0) p.stagger = stagger_env;
+int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "td_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   const int esz = p.fp8 ? 1 : 2;
   TD_CHECK_ARG(p.K % (128 / esz) == 0, "td_gemm: K=%d must be a multiple of %d", p.K, 128 / esz);

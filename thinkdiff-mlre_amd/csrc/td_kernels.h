@@ -34,7 +34,6 @@ struct TdGemmParams {
   int fp8 = 0;
   const float* a_scale = nullptr; const float* w_scale = nullptr;        // [M], [N]
   const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch
-  int stagger = 0;               // bf16 tile kernel: waves 4-7 run their MFMAs half a k-tile behind waves 0-3 (see the kernel)
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
 };
 
