@@ -92,8 +92,20 @@ def cpu_baseline(threads: int):
         "sample": (f"oracle/flux_ref.py (torch CPU bf16, the reference pipeline's arithmetic): 1 double-stream block "
                    f"({t_d:.2f} s) + 1 single-stream block ({t_s:.2f} s) of FLUX.1-dev at S_img={s_img}, T={T_TXT}, best of {reps} reps, {threads} threads; "
                    f"extrapolated x(19, 38) blocks x {NUM_STEPS} steps" + ("" if s_img == 4096 else f" x{k:.2f} FLOP ratio to S_img=4096")
-                   + f" = {sec_per_image:.0f} s/image"),
+                   + f" = {sec_per_image:.0f} s/image" + _whole_run_note()),
     }
+
+
+def _whole_run_note():
+    """The one directly measured whole run of this workload on a CPU: the 28-step, full-depth oracle trajectory that became the
+    parity fixture (tests/golden/make_full_depth_golden.py, build container).  Quoted beside the extrapolated sample as a cross-check."""
+    fn = os.path.join(ROOT, "tests", "golden", "full_depth_cfg2_T193.pt")
+    try:
+        fx = torch.load(fn)
+        return (f"; cross-check: the whole 28-step 1024x1024 oracle run measured once in the build container took {fx['oracle_seconds']:.0f} s "
+                f"on {fx['oracle_threads']} cores (tests/golden/full_depth_cfg2_T193.pt)")
+    except Exception:  # noqa: BLE001
+        return ""
 
 
 def fp8_leg(pipe, G, rank, steps=2):

@@ -184,7 +184,10 @@ int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, c
  * output channel from the parameters as loaded NOW (call after loading; call again after reloading) and runs those GEMMs on
  * the fp8 MFMA path with per-token dynamic activation scales (BASELINE config 5).  Accumulation, epilogues, attention,
  * normalisation and the residual stream stay as in the bf16 path. */
-enum { TD_PRECISION_BF16 = 0, TD_PRECISION_FP8_E4M3 = 1 };
+enum { TD_PRECISION_BF16 = 0, TD_PRECISION_FP8_E4M3 = 1,
+       /* W8A8 symmetric int8 (round 3): the same per-output-channel weight / per-token activation scaling and the same 2x-bf16 MFMA
+        * rate (v_mfma_i32_16x16x64_i8, exact int32 accumulation), with a uniform step of max/127 instead of e4m3's 3-bit mantissa */
+       TD_PRECISION_INT8 = 2 };
 int td_flux_set_precision(td_flux* f, int precision, void* stream);
 /* Which block Linears take the fp8 path while the precision is TD_PRECISION_FP8_E4M3 (default: all).  The rest run in bf16 from
  * the bf16 weights: a speed / deviation-from-bf16 trade.  Parent context only; takes effect at the next step. */
@@ -222,6 +225,13 @@ int td_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* s
 int td_linear_fp8(const void* xq, int64_t ldx, const float* x_scale, const void* wq, const float* w_scale, const void* bias,
                   void* y, int64_t ldy, int M, int N, int K, int act, const void* gate, const void* res, int64_t ldr,
                   int tile_cfg, void* stream);
+/* ---- int8 operand path (round 3; TD_PRECISION_INT8) -- the 8-bit form whose pixels stay inside the 1e-2 bar at full coverage -----
+ * Same scaling scheme and call shape as the fp8 entries: q[r,:] = rint(x[r,:] / s_r) as int8, s_r = max|x[r,:]| / 127 (1 for an
+ * all-zero row); the contraction runs on v_mfma_i32_16x16x64_i8 (exact int32 accumulation) at twice the bf16 MFMA rate. */
+int td_quant_rows_int8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream);
+int td_linear_int8(const void* xq, int64_t ldx, const float* x_scale, const void* wq, const float* w_scale, const void* bias,
+                   void* y, int64_t ldy, int M, int N, int K, int act, const void* gate, const void* res, int64_t ldr,
+                   int tile_cfg, void* stream);
 /* td_norm_rows_bf16 whose output row is quantised in registers: q [rows, ldq] e4m3 + q_scale[rows] (no bf16 copy). */
 int td_norm_rows_quant_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* q_scale, int rows, int D, int rms, float eps,
                            const void* w, int split, const void* shiftA, const void* scaleA, const void* shiftB, const void* scaleB,

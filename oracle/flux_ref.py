@@ -163,12 +163,25 @@ def _quant_rows_e4m3(x2d):
     return (xf * (1.0 / s)[:, None]).to(torch.float8_e4m3fn).float(), s
 
 
+# int8 operand mode (restates td_flux_set_precision(TD_PRECISION_INT8)): the same Linears, symmetric int8 operands -- weights per
+# output channel, activations per token, scale = max|.| / 127, q = round-half-even(x / scale) -- exact integer accumulation.
+INT8_BLOCK_LINEARS = False
+
+
+def _quant_rows_int8(x2d):
+    xf = x2d.float()
+    amax = xf.abs().amax(dim=1)
+    s = torch.where(amax > 0, amax * (1.0 / 127.0), torch.ones_like(amax))
+    return torch.round(xf * (1.0 / s)[:, None]).clamp_(-127, 127), s
+
+
 def _lin(sd, name, x):
     w, b = sd[name + ".weight"], sd[name + ".bias"]
     in_block = name.startswith(("transformer_blocks.", "single_transformer_blocks."))
-    if FP8_BLOCK_LINEARS and in_block and ".norm" not in name:
-        xq, sx = _quant_rows_e4m3(x.reshape(-1, x.shape[-1]))
-        wq, sw = _quant_rows_e4m3(w)
+    if (FP8_BLOCK_LINEARS or INT8_BLOCK_LINEARS) and in_block and ".norm" not in name:
+        quant = _quant_rows_int8 if INT8_BLOCK_LINEARS else _quant_rows_e4m3
+        xq, sx = quant(x.reshape(-1, x.shape[-1]))
+        wq, sw = quant(w)
         y = (xq.double() @ wq.double().T).float() * sx[:, None] * sw[None, :] + b.float()
         return y.to(x.dtype).reshape(*x.shape[:-1], w.shape[0])
     return F.linear(x, w, b)

@@ -144,7 +144,7 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
     lat = R.pack_latents(raw.cpu()).cuda()
     tr = pipe.transformer
     res = {}
-    for prec, gemms in (("bf16", None), ("fp8", None), ("fp8_single", ["single_in", "single_out"])):
+    for prec, gemms in (("bf16", None), ("fp8", None), ("fp8_single", ["single_in", "single_out"]), ("int8", None)):
         tr.set_precision(prec.split("_")[0], fp8_gemms=gemms)
         out = pipe(prompt_embeds=pe, pooled_prompt_embeds=pool, height=1024, width=1024, num_inference_steps=28, guidance_scale=3.5,
                    latents=lat, output_type="latent").images[0].clone()
@@ -153,7 +153,7 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
         assert torch.isfinite(out.float()).all()
         res[prec] = {"latent_rel_rmse_vs_oracle": _rel_rmse(out, fx["latents"][-1]), "pixel_rmse_vs_oracle": _px_rmse(u8, fx["image_u8"]), "u8": u8}
     tr.set_precision("bf16")
-    for k in ("fp8", "fp8_single"):
+    for k in ("fp8", "fp8_single", "int8"):
         res[k]["pixel_rmse_vs_hip_bf16"] = _px_rmse(res[k]["u8"], res["bf16"]["u8"])
     for k, v in res.items():
         v.pop("u8")
@@ -162,6 +162,8 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
     # the ordering that must hold whatever the absolute level: more fp8 Linears -> further from the oracle
     assert res["bf16"]["pixel_rmse_vs_oracle"] <= res["fp8_single"]["pixel_rmse_vs_oracle"] <= res["fp8"]["pixel_rmse_vs_oracle"]
     assert res["fp8"]["pixel_rmse_vs_oracle"] < float(os.environ.get("TD_FP8_PIXEL_BAR", "3e-2")), "all-fp8 pixels left the recorded level"
+    # the 8-bit mode that holds the north-star bar with EVERY block Linear quantised: symmetric int8 (uniform step, exact accumulation)
+    assert res["int8"]["pixel_rmse_vs_oracle"] < 1e-2, f"int8 pixels {res['int8']['pixel_rmse_vs_oracle']:.4f} from the oracle fixture exceed the 1e-2 bar"
 
 
 def test_full_width_block_pair_config5_shape(hip):

@@ -1,0 +1,107 @@
+"""int8 operand path (TD_PRECISION_INT8, round 3): the quantiser bit-exact against its torch statement, the int8 GEMM against the
+exact integer contraction of the very same quantised operands (int32 accumulation is exact, so only the dequantisation and the
+bf16 output rounding remain), the end-to-end quantisation error against the bf16 GEMM, and the FLUX engine in int8 mode against
+the oracle's int8 switch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _quant_ref(x):
+    """per-row symmetric int8 exactly as csrc/elementwise.hip states it (fp32 arithmetic, round half to even)."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    s = torch.where(amax > 0, amax * (1.0 / 127.0), torch.ones_like(amax))
+    return torch.round(xf * (1.0 / s)[:, None]).clamp(-127, 127).to(torch.int8), s
+
+
+def test_quant_rows_int8_bit_exact(hip):
+    torch.manual_seed(0)
+    x = (torch.randn(77, 3072, device="cuda") * torch.logspace(-3, 2, 77, device="cuda")[:, None]).bfloat16()
+    x[5] = 0
+    x[6, 17] = 3.0e4
+    q, s = hip.quant_rows_int8(x)
+    torch.cuda.synchronize()
+    qr, sr = _quant_ref(x)
+    assert torch.equal(s, sr)
+    assert torch.equal(q, qr)
+    assert s[5] == 1.0 and not q[5].any() and int(q.abs().max()) == 127
+
+
+@pytest.mark.parametrize("M,N,K,cfg", [(4289, 3072, 3072, -1), (193, 768, 1024, -1), (777, 1536, 6144, 3), (20, 512, 256, 2), (1000, 9216, 3072, 0)])
+def test_linear_int8_matches_integer_contraction(hip, M, N, K, cfg):
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda").bfloat16()
+    xq, xs = hip.quant_rows_int8(x)
+    wq, ws = hip.quant_rows_int8(w)
+    y = hip.linear_int8(xq, xs, wq, ws, b, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    acc = xq.double() @ wq.double().T                                 # exact: |sum| < 2^31 for K <= 133k
+    want = (acc * xs.double()[:, None] * ws.double()[None, :] + b.double()).float()
+    err = (y.float() - want).abs().max() / want.abs().max()
+    assert err < 2 ** -7, err             # one bf16 rounding of the output
+    ref = hip.linear(x, w, b)
+    torch.cuda.synchronize()
+    rel = float((y.float() - ref.float()).pow(2).mean().sqrt() / ref.float().pow(2).mean().sqrt())
+    print(f"int8 vs bf16 GEMM rel-RMSE {rel:.4f}")
+    assert rel < 1.5e-2                   # uniform step max/127 on both operands: ~1 % for gaussian data (e4m3: ~5 %)
+
+
+def test_linear_int8_epilogues(hip):
+    torch.manual_seed(9)
+    M, N, K = 300, 1024, 512
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda").bfloat16()
+    g = torch.randn(N, device="cuda").bfloat16()
+    r = torch.randn(M, N, device="cuda").bfloat16()
+    xq, xs = hip.quant_rows_int8(x)
+    wq, ws = hip.quant_rows_int8(w)
+    lin = ((xq.float() @ wq.float().T) * xs[:, None] * ws[None, :] + b.float()).bfloat16()
+    got = hip.linear_int8(xq, xs, wq, ws, b, gate=g, res=r)
+    want = ((lin * g).float() + r.float())
+    got2 = hip.linear_int8(xq, xs, wq, ws, b, act=hip.ACT_GELU_TANH)
+    want2 = torch.nn.functional.gelu(lin.float(), approximate="tanh")
+    torch.cuda.synchronize()
+    assert (got.float() - want).abs().max() <= 2 ** -6 * want.abs().max()
+    assert (got2.float() - want2).abs().max() <= 2 ** -6 * want2.abs().max()
+
+
+def test_int8_mode_matches_int8_oracle(hip):
+    """The engine in int8 mode against oracle/flux_ref.py with INT8_BLOCK_LINEARS (tiny config, one forward)."""
+    from oracle import flux_ref as R
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig
+    cfg = R.tiny_config(num_layers=2, num_single_layers=2)
+    sd = R.init_weights(cfg, seed=4)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=2, num_single_layers=2, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    h2 = w2 = 12
+    T = 40
+    lat = torch.randn(1, h2 * w2, 64, generator=g).bfloat16()
+    pe = torch.randn(1, T, cfg.joint_attention_dim, generator=g).bfloat16()
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g).bfloat16()
+    img_ids, txt_ids = R.latent_image_ids(h2, w2), torch.zeros(T, 3)
+    t, gd = torch.tensor([0.7324]), torch.tensor([3.5])
+    with torch.no_grad():
+        ref16 = R.transformer_forward(sd, cfg, lat, pe, pool, t.bfloat16(), img_ids.bfloat16(), txt_ids.bfloat16(), gd)
+        R.INT8_BLOCK_LINEARS = True
+        try:
+            ref8 = R.transformer_forward(sd, cfg, lat, pe, pool, t.bfloat16(), img_ids.bfloat16(), txt_ids.bfloat16(), gd)
+        finally:
+            R.INT8_BLOCK_LINEARS = False
+    rel = lambda a, b: float((a.float().cpu() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt())
+    out16 = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, gd)[0].clone()
+    m.set_precision("int8")
+    out8 = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, gd)[0].clone()
+    m.set_precision("bf16")
+    torch.cuda.synchronize()
+    e16, e88, d_hip, d_ref = rel(out16, ref16[0]), rel(out8, ref8[0]), rel(out8, out16.cpu()), rel(ref8[0], ref16[0])
+    print(f"tiny config: hip~bf16-oracle {e16:.4f}  hip-int8~oracle-int8 {e88:.4f}  int8~bf16 hip {d_hip:.4f} oracle {d_ref:.4f}")
+    assert e16 < 2e-2 and e88 < 2e-2
+    assert d_hip < 3e-2 and abs(d_hip - d_ref) < 0.5 * d_ref + 2e-3

@@ -241,6 +241,20 @@ int td_linear_fp8(const void* xq, int64_t ldx, const float* x_scale, const void*
   p.M = M; p.N = N; p.K = K; p.act = act; p.cfg = tile_cfg;
   return td_gemm_launch(p, (hipStream_t)stream);
 }
+int td_quant_rows_int8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows, int K, void* stream) {
+  return td_quant_rows_fp8_launch((const bf16_t*)x, (int)ldx, (uint8_t*)q, (int)ldq, scale, rows, K, (hipStream_t)stream, 1);
+}
+int td_linear_int8(const void* xq, int64_t ldx, const float* x_scale, const void* wq, const float* w_scale, const void* bias,
+                   void* y, int64_t ldy, int M, int N, int K, int act, const void* gate, const void* res, int64_t ldr,
+                   int tile_cfg, void* stream) {
+  TdGemmParams p;
+  p.i8 = 1; p.A = (const bf16_t*)xq; p.lda = (int)ldx; p.a_scale = x_scale;
+  p.W = (const bf16_t*)wq; p.w_scale = w_scale; p.bias = (const bf16_t*)bias;
+  p.C = (bf16_t*)y; p.ldc = (int)ldy;
+  p.gate = (const bf16_t*)gate; p.res = (const bf16_t*)res; p.ldr = (int)ldr;
+  p.M = M; p.N = N; p.K = K; p.act = act; p.cfg = tile_cfg;
+  return td_gemm_launch(p, (hipStream_t)stream);
+}
 int td_norm_rows_quant_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* q_scale, int rows, int D, int rms, float eps,
                            const void* w, int split, const void* shiftA, const void* scaleA, const void* shiftB, const void* scaleB,
                            void* stream) {

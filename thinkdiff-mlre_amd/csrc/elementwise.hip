@@ -31,6 +31,18 @@ __device__ __forceinline__ u32x2_t pack8_fp8(const float (&x)[8], float inv) {
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv, x[7] * inv, hi, true);
   return u32x2_t{(unsigned)lo, (unsigned)hi};
 }
+// 8 floats * inv -> 8 symmetric int8 bytes (round to nearest even; |x * inv| <= 127 by construction)
+__device__ __forceinline__ u32x2_t pack8_i8(const float (&x)[8], float inv) {
+  unsigned w[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const unsigned b0 = (unsigned)__float2int_rn(x[4 * h] * inv) & 0xffu, b1 = (unsigned)__float2int_rn(x[4 * h + 1] * inv) & 0xffu;
+    const unsigned b2 = (unsigned)__float2int_rn(x[4 * h + 2] * inv) & 0xffu, b3 = (unsigned)__float2int_rn(x[4 * h + 3] * inv) & 0xffu;
+    w[h] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+  }
+  return u32x2_t{w[0], w[1]};
+}
+__device__ __forceinline__ u32x2_t pack8_q(const float (&x)[8], float inv, bool int8) { return int8 ? pack8_i8(x, inv) : pack8_fp8(x, inv); }
 
 // ---------------------------------------------------------------------------------------------
 // Row normalisation (+ optional affine weight, + optional adaLN modulation), one wave per row.
@@ -104,12 +116,12 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
   }
   if (p.q) {
     amax = wave_max(amax);
-    const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float s = amax > 0.f ? amax * (p.q_int8 ? 1.0f / 127.0f : 1.0f / 448.0f) : 1.0f;
     const float inv = 1.0f / s;
     if (lane == 0) p.q_scale[row] = s;
     uint8_t* qr = p.q + (size_t)row * p.ldq;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) *(u32x2_t*)(qr + c * 512 + lane * 8) = pack8_fp8(v[c], inv);
+    for (int c = 0; c < NCH; ++c) *(u32x2_t*)(qr + c * 512 + lane * 8) = pack8_q(v[c], inv, p.q_int8 != 0);
   }
 }
 
@@ -662,7 +674,7 @@ int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, floa
 
 
 // ---- per-row dynamic fp8 (OCP e4m3) quantisation: weights at load time (per output channel), activations per token ----
-__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K) {
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, int int8) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -675,20 +687,20 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x,
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
   }
   amax = wave_max(amax);
-  const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float s = amax > 0.f ? amax * (int8 ? 1.0f / 127.0f : 1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / s;
   if (lane == 0) scale[row] = s;
   uint8_t* qr = q + (size_t)row * ldq;
   for (int c = lane * 8; c < K; c += 512) {
     float v[8];
     unpack8(*(const u32x4_t*)(xr + c), v);
-    *(u32x2_t*)(qr + c) = pack8_fp8(v, inv);
+    *(u32x2_t*)(qr + c) = pack8_q(v, inv, int8 != 0);
   }
 }
 
 // the same with the row held in registers between the amax pass and the conversion (K = NCH * 512 <= 16384): one read of x
 template <int NCH>
-__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows) {
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int int8) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -702,7 +714,7 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t
 #pragma unroll
     for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(raw[c][i])), fabsf(bf_hi(raw[c][i]))));
   amax = wave_max(amax);
-  const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float s = amax > 0.f ? amax * (int8 ? 1.0f / 127.0f : 1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / s;
   if (lane == 0) scale[row] = s;
   uint8_t* qr = q + (size_t)row * ldq + lane * 8;
@@ -710,19 +722,19 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t
   for (int c = 0; c < NCH; ++c) {
     float v[8];
     unpack8(raw[c], v);
-    *(u32x2_t*)(qr + c * 512) = pack8_fp8(v, inv);
+    *(u32x2_t*)(qr + c * 512) = pack8_q(v, inv, int8 != 0);
   }
 }
 
-int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream) {
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8) {
   TD_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_fp8: bad arguments");
   TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_quant_rows_fp8");
   const dim3 grid(nblk), block(256);
   switch (K % 512 == 0 ? K / 512 : 0) {
-#define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows); break;
+#define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, int8); break;
     TD_CASE(1) TD_CASE(2) TD_CASE(4) TD_CASE(6) TD_CASE(8) TD_CASE(24) TD_CASE(30)
 #undef TD_CASE
-    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K);
+    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K, int8);
   }
   TD_CHECK_LAUNCH();
   return 0;

@@ -167,7 +167,9 @@ int gemm8(td_flux* f, hipStream_t s, const uint8_t* A, int lda, const float* a_s
           int M, int N, int K, int act = TD_ACT_NONE, const bf16_t* gate = nullptr, const bf16_t* res = nullptr, int ldr = 0,
           bf16_t* C2 = nullptr, int ldc2 = 0, int act2 = TD_ACT_NONE, int n_split = 0) {
   TdGemmParams p;
-  p.fp8 = 1; p.A = (const bf16_t*)A; p.lda = lda; p.a_scale = a_scale; p.W = (const bf16_t*)W.q; p.w_scale = W.s;
+  const td_flux* root8 = f->parent ? f->parent : f;
+  p.fp8 = root8->precision == TD_PRECISION_FP8_E4M3; p.i8 = root8->precision == TD_PRECISION_INT8;
+  p.A = (const bf16_t*)A; p.lda = lda; p.a_scale = a_scale; p.W = (const bf16_t*)W.q; p.w_scale = W.s;
   p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.n_split = n_split;
   const int cfg = td_gemm_config_id(M, N, K / 2);
@@ -178,7 +180,8 @@ int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, cons
             const uint8_t* A1, const float* as1, const Fp8Mat& W1, const bf16_t* b1, bf16_t* C1, int M1, int ld_a, int ld_c, int N, int K,
             int act = TD_ACT_NONE, const bf16_t* gate0 = nullptr, const bf16_t* gate1 = nullptr, bool residual = false) {
   TdGemmParams p;
-  p.fp8 = 1;
+  const td_flux* root8 = f->parent ? f->parent : f;
+  p.fp8 = root8->precision == TD_PRECISION_FP8_E4M3; p.i8 = root8->precision == TD_PRECISION_INT8;
   p.A = (const bf16_t*)A0; p.a_scale = as0; p.W = (const bf16_t*)W0.q; p.w_scale = W0.s; p.bias = b0; p.C = C0; p.M = M0;
   p.gate = gate0; p.res = residual ? C0 : nullptr;
   p.g_A = (const bf16_t*)A1; p.g_a_scale = as1; p.g_W = (const bf16_t*)W1.q; p.g_w_scale = W1.s; p.g_bias = b1; p.g_C = C1; p.g_M = M1;
@@ -191,7 +194,7 @@ int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, cons
 // per-token quantisation of a bf16 activation matrix into f->aq / f->as_
 int quant_act(td_flux* f, hipStream_t s, const bf16_t* x, int ldx, int rows, int K) {
   TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
-  return td_quant_rows_fp8_launch(x, ldx, f->aq, K, f->as_, rows, K, s);
+  return td_quant_rows_fp8_launch(x, ldx, f->aq, K, f->as_, rows, K, s, (f->parent ? f->parent : f)->precision == TD_PRECISION_INT8);
 }
 
 int norm_rows(td_flux* f, hipStream_t s, const TdNormParams& p) {
@@ -441,7 +444,7 @@ int td_flux_set_fp8_gemms(td_flux* f, unsigned mask) {
 }
 
 int td_flux_set_precision(td_flux* f, int precision, void* stream) {
-  TD_CHECK_ARG(f && (precision == TD_PRECISION_BF16 || precision == TD_PRECISION_FP8_E4M3), "td_flux_set_precision: unknown precision %d", precision);
+  TD_CHECK_ARG(f && (precision == TD_PRECISION_BF16 || precision == TD_PRECISION_FP8_E4M3 || precision == TD_PRECISION_INT8), "td_flux_set_precision: unknown precision %d", precision);
   TD_CHECK_ARG(!f->parent, "td_flux_set_precision: set the precision on the parent context (forks follow it)");
   if (precision == TD_PRECISION_BF16) { f->precision = precision; return TD_OK; }
   TD_CHECK_ARG(f->D % 128 == 0 && f->M % 128 == 0, "td_flux_set_precision: fp8 needs inner widths that are multiples of 128");
@@ -473,7 +476,7 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream) {
     for (auto& w : f->sgl8) { w.w1 = take(3 * D + M, D); w.w2 = take(D, D + M); }
   }
   auto qz = [&](const bf16_t* w, const Fp8Mat& m, int64_t rows, int64_t K) {
-    return td_quant_rows_fp8_launch(w, (int)K, m.q, (int)K, m.s, (int)rows, (int)K, s);
+    return td_quant_rows_fp8_launch(w, (int)K, m.q, (int)K, m.s, (int)rows, (int)K, s, precision == TD_PRECISION_INT8);
   };
   for (int i = 0; i < L; ++i) {
     const DoubleW& w = f->dbl[i];
@@ -628,10 +631,11 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   // fp8 mode: the LayerNorm-modulate kernel emits e4m3 rows + per-token scales directly; attention / MLP outputs
   // get a per-token quantisation pass; every block GEMM then runs on the fp8 MFMA path.
   const td_flux* root = f->parent ? f->parent : f;   // weights and precision live in the parent context
-  const unsigned m8 = root->precision == TD_PRECISION_FP8_E4M3 ? root->fp8_mask : 0u;      // per Linear class
+  const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
+  const int q_int8 = root->precision == TD_PRECISION_INT8;
   // the LayerNorm ahead of an fp8 Linear writes e4m3 rows + scales, ahead of a bf16 one the bf16 rows
   auto norm_for = [&](bool fp8) {
-    if (fp8) { np.q = f->xq; np.ldq = D; np.q_scale = f->xs; } else { np.q = nullptr; np.q_scale = nullptr; }
+    if (fp8) { np.q = f->xq; np.ldq = D; np.q_scale = f->xs; np.q_int8 = q_int8; } else { np.q = nullptr; np.q_scale = nullptr; }
   };
   for (int i = 0; i < L; ++i) {
     const DoubleW& w = f->dbl[i];

@@ -215,7 +215,12 @@ __device__ __forceinline__ void epilogue_f32(const TdGemmParams& pp, const ProbV
 // v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 MFMA rate).  The k <-> (lane, byte) map of the
 // instruction does not matter: both operands are read with the same map and the contraction sums over all k.
 // Dequantisation is per output row (a_scale[m]) x per output column (w_scale[n]) on the fp32 accumulators.
-template <int WM, int WN, bool CONV = false, bool FP8 = false>
+// INT8 (I8): both operands are symmetric int8 bytes.  v_mfma_i32_16x16x64_i8 takes the SAME 16-byte fragments per lane and k-step as
+// the bf16 instruction (64 int8 instead of 32 bf16 per k-step, twice the rate), so the int8 kernel IS the bf16 main loop -- staging,
+// swizzle, W ring, instruction interleave -- with the other MFMA and k-tiles of 128 elements; the int32 accumulators are exact and
+// become floats (x a_scale[m] x w_scale[n]) in front of the common epilogue.  Round 3: 8-bit operands whose quantisation noise is
+// ~4x below e4m3's on Gaussian-like operands (uniform step max/127 against a 3-bit mantissa).
+template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   constexpr int BM = 32 * WM, BN = 64 * WN;
@@ -223,8 +228,9 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   constexpr int GA = BM / 8, GW = BN / 8;           // 8-row staging groups per tile
   constexpr int SA = (GA + 7) / 8, SW = (GW + 7) / 8;  // staging instructions per wave
   constexpr int NV = 4 * WN;                          // contiguous output columns per lane
-  constexpr unsigned ESZ = FP8 ? 1u : 2u;             // operand element size in bytes
-  static_assert(!FP8 || !CONV, "no fp8 convolution");
+  constexpr unsigned ESZ = (FP8 || I8) ? 1u : 2u;     // operand element size in bytes
+  static_assert(!(FP8 || I8) || !CONV, "no 8-bit convolution");
+  static_assert(!(FP8 && I8), "one operand type");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 #pragma unroll
     for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / (FP8 ? 2 * BK : BK);      // a k-tile is one 128-B row: 64 bf16 or 128 fp8
+  const int nt = p.K / ((FP8 || I8) ? 2 * BK : BK);      // a k-tile is one 128-B row: 64 bf16 or 128 fp8 / int8
 #pragma unroll
   for (int s = 0; s < NS; ++s) stage_one(s, 0, 0, 0);
   if constexpr (FP8) {
@@ -476,8 +482,15 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
             }
         }
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[cur], acc[j][i], 0, 0, 0);
+        for (int j = 0; j < WN; ++j) {
+          if constexpr (I8) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            acc[j][i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, wf[ks][j]), __builtin_bit_cast(i32x4_t, af[cur]),
+                                                                                           __builtin_bit_cast(i32x4_t, acc[j][i]), 0, 0, 0));
+          } else {
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[cur], acc[j][i], 0, 0, 0);
+          }
+        }
         const int nreads = ((i + 1 < WM || ks == 0) ? 1 : 0) + nwf;
         switch (nst) {  // the builtin wants literal counts
           case 1: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 1, 0); break;
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   const bool second = (p.C2 != nullptr) && (n0 >= p.n_split);
   const int act = second ? p.act2 : p.act;
   const int mbeg = m0 + wr * 16 * WM + frow;
-  if constexpr (FP8) {   // y = (sum q_a q_w) * a_scale[row] * w_scale[col]
+  if constexpr (FP8 || I8) {   // y = (sum q_a q_w) * a_scale[row] * w_scale[col]
     // range-checked loads: rows >= M / columns >= N read a zero scale (their outputs are dropped anyway)
     const __amdgpu_buffer_rsrc_t rsSa = make_rsrc(second_prob ? p.g_a_scale : p.a_scale, (unsigned)pv.M * 4u);
     const __amdgpu_buffer_rsrc_t rsSw = make_rsrc(second_prob ? p.g_w_scale : p.w_scale, (unsigned)p.N * 4u);
@@ -522,7 +535,10 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[j][i][r] *= sr * swv[j * 4 + r];
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (I8) acc[j][i][r] = (float)(int)as_u32(acc[j][i][r]) * (sr * swv[j * 4 + r]);     // exact int32 sum -> float
+          else acc[j][i][r] *= sr * swv[j * 4 + r];
+        }
     }
   }
   // (an activation followed by a gate / residual does not occur on this path: act wins)
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
 
 namespace {
 
-template <int WM, int WN, bool CONV = false, bool FP8 = false>
+template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int LDS = (2 * BM + 3 * BN) * ROW_BYTES;
@@ -551,12 +567,12 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   int dev = 0;
   TD_CHECK_HIP(hipGetDevice(&dev));
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8>,
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
@@ -580,7 +596,8 @@ int td_gemm_config_id(int M, int N, int K) {
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "td_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
-  const int esz = p.fp8 ? 1 : 2;
+  const int esz = (p.fp8 || p.i8) ? 1 : 2;
+  TD_CHECK_ARG(!(p.fp8 && p.i8), "td_gemm: fp8 and int8 operands are exclusive");
   TD_CHECK_ARG(p.K % (128 / esz) == 0, "td_gemm: K=%d must be a multiple of %d", p.K, 128 / esz);
   TD_CHECK_ARG(p.N % 8 == 0, "td_gemm: N=%d must be a multiple of 8", p.N);
   TD_CHECK_ARG((p.conv_H > 0 || p.lda >= p.K) && p.ldc >= (p.C2 ? p.n_split : p.N), "td_gemm: bad leading dimensions");
@@ -608,11 +625,20 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   }
   // M <= 64 without a tile override is a weight stream, not a tile problem (Qwen2-VL decode of up to 64 sequences, embedders, lm_head)
   if (p.glu_I) {
-    TD_CHECK_ARG(p.M <= 64 && p.g_M == 0 && !p.fp8 && !p.out_f32 && p.conv_H == 0, "td_gemm: the gated form exists for the skinny-M kernels only (M <= 64)");
+    TD_CHECK_ARG(p.M <= 64 && p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.conv_H == 0, "td_gemm: the gated form exists for the skinny-M kernels only (M <= 64)");
     return td_gemv_launch(p, stream);
   }
-  if (p.g_M == 0 && !p.fp8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
+  if (p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
+  if (p.i8) {
+    TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,
+                 "td_gemm(int8): row / column dequantisation scales are required; no conv / fp32-out form");
+    switch (cfg) {
+      case 2: return launch_cfg<1, 4, false, false, true>(p, stream);
+      case 3: return launch_cfg<9, 3, false, false, true>(p, stream);
+      default: return launch_cfg<8, 4, false, false, true>(p, stream);
+    }
+  }
   if (p.fp8) {
     TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,
                  "td_gemm(fp8): row / column dequantisation scales are required; no conv / fp32-out form");

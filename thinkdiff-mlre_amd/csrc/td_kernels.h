@@ -32,6 +32,9 @@ struct TdGemmParams {
   // C[m, n] = bf16(bf16(silu(bf16(x.gate_n))) * bf16(x.up_n)) -- Linear, SiLU and the product each round, as the separate kernels do
   int glu_I = 0;
   int fp8 = 0;
+  // int8 operands (i8 = 1): A and W hold symmetric int8 (lda, K in elements = bytes), v_mfma_i32_16x16x64_i8, exact int32 accumulation;
+  // y = float(acc) * a_scale[m] * w_scale[n] -- the same scale arrays and the same 2x-bf16 MFMA rate as the fp8 form
+  int i8 = 0;
   const float* a_scale = nullptr; const float* w_scale = nullptr;        // [M], [N]
   const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
@@ -90,9 +93,11 @@ struct TdNormParams {
   const bf16_t* shiftB = nullptr; const bf16_t* scaleB = nullptr;
   // fp8 output (q != null): the row is written as OCP e4m3 q[row, :] = fp8(y / s), s = max|y| / 448 -> q_scale[row]; y unused
   uint8_t* q = nullptr; int ldq = 0; float* q_scale = nullptr;
+  int q_int8 = 0;   // q holds symmetric int8 instead: q = rint(y / s), s = max|y| / 127
 };
 // per-row dynamic fp8 quantisation of a bf16 matrix: q[r,:] = e4m3(x[r,:] / s_r), s_r = max|x[r,:]| / 448 (1 for a zero row)
-int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream);
+// int8 = 1: symmetric int8 instead (q = rint(x / s_r), s_r = max|x[r,:]| / 127)
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8 = 0);
 int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream);
 
 struct TdQkRopeParams {

@@ -71,6 +71,8 @@ def _declare(L):
         "td_attention_decode_set_group": [i32],
         "td_quant_rows_fp8": [vp, i64, vp, i64, vp, i32, i32, vp],
         "td_linear_fp8": [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, i32, vp],
+        "td_quant_rows_int8": [vp, i64, vp, i64, vp, i32, i32, vp],
+        "td_linear_int8": [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, i32, vp],
         "td_norm_rows_quant_fp8": [vp, i64, vp, i64, vp, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp],
         "td_layernorm_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, vp, vp, vp],
         "td_add_rows_bf16": [vp, vp, vp, i32, i32, i32, vp],
@@ -444,6 +446,26 @@ def linear_fp8(xq, xs, wq, ws, bias=None, act=ACT_NONE, gate=None, res=None, out
         out = torch.empty(M, N, dtype=torch.bfloat16, device=xq.device)
     check(lib().td_linear_fp8(ptr(xq), xq.stride(0), ptr(xs), ptr(wq), ptr(ws), ptr(bias), ptr(out), _rows(out), M, N, K, act,
                               ptr(gate), ptr(res), _rows(res) if res is not None else 0, tile_cfg, stream_ptr()))
+    return out
+
+
+def quant_rows_int8(x):
+    """bf16 [R,K] -> (int8 [R,K], fp32 scale [R]): q = rint(x / s), s = max|x| / 127 per row."""
+    R, K = x.shape
+    q = torch.empty(R, K, dtype=torch.int8, device=x.device)
+    s = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(lib().td_quant_rows_int8(ptr(x), _rows(x), ptr(q), K, ptr(s), R, K, stream_ptr()))
+    return q, s
+
+
+def linear_int8(xq, xs, wq, ws, bias=None, act=ACT_NONE, gate=None, res=None, out=None, tile_cfg=-1):
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert xq.dtype == torch.int8 and wq.dtype == torch.int8 and wq.shape[1] == K and wq.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=xq.device)
+    check(lib().td_linear_int8(ptr(xq), xq.stride(0), ptr(xs), ptr(wq), ptr(ws), ptr(bias), ptr(out), _rows(out), M, N, K, act,
+                               ptr(gate), ptr(res), _rows(res) if res is not None else 0, tile_cfg, stream_ptr()))
     return out
 
 

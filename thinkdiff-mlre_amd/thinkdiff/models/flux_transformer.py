@@ -153,11 +153,11 @@ class FluxTransformer2DModel:
         parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly).
         fp8_gemms: None = every block Linear, or the classes that take the fp8 path (names of FP8_GEMMS, or the bit mask);
         the others stay bf16."""
-        code = {"bf16": 0, "bfloat16": 0, "fp8": 1, "fp8_e4m3": 1, "float8_e4m3fn": 1}[str(precision).replace("torch.", "")]
+        code = {"bf16": 0, "bfloat16": 0, "fp8": 1, "fp8_e4m3": 1, "float8_e4m3fn": 1, "int8": 2, "w8a8": 2}[str(precision).replace("torch.", "")]
         _hip.check(self._L.td_flux_set_precision(self._h, code, _hip.stream_ptr()))
         mask = 63 if fp8_gemms is None else (int(fp8_gemms) if isinstance(fp8_gemms, int) else sum(self.FP8_GEMMS[str(n)] for n in fp8_gemms))
         _hip.check(self._L.td_flux_set_fp8_gemms(self._h, mask))
-        self.precision, self.fp8_gemms = ("fp8" if code else "bf16"), mask
+        self.precision, self.fp8_gemms = ("bf16", "fp8", "int8")[code], mask
         return self
 
     # ---- conditioning / schedule ----------------------------------------------------------------------
