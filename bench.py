@@ -31,6 +31,7 @@ GUIDANCE = 3.5
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FP8_DENSE_PEAK_TFLOPS = 5000.0
 FP8_DTYPE = "fp8_e4m3 block-GEMM operands, fp32 accumulate, bf16 elsewhere"
+INT8_DTYPE = "int8 block-GEMM operands (symmetric W8A8), exact int32 accumulate, bf16 elsewhere"
 
 
 def flux_flops_per_forward(s_img: int, s_txt: int) -> float:
@@ -125,8 +126,8 @@ def fp8_leg(pipe, G, rank, steps=2):
         return pipe(prompt_embeds=pe[:n], pooled_prompt_embeds=pooled[:n], num_images_per_prompt=1, height=HEIGHT, width=WIDTH,
                     num_inference_steps=NUM_STEPS, guidance_scale=GUIDANCE, latents=packed[:n], output_type="pil").images
 
-    def measure(fp8_gemms):
-        tr.set_precision("fp8", fp8_gemms=fp8_gemms)
+    def measure(fp8_gemms, precision="fp8"):
+        tr.set_precision(precision, fp8_gemms=fp8_gemms)
         run(G)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -145,6 +146,7 @@ def fp8_leg(pipe, G, rank, steps=2):
 
     el, single = measure(None)                                     # every block Linear in fp8
     el_s, single_s = measure(["single_in", "single_out"])          # the 38 single-stream blocks in fp8, the 19 double-stream ones in bf16
+    el_i, single_i = measure(None, "int8")                         # every block Linear on symmetric int8 operands (TD_PRECISION_INT8)
     tr.set_precision("bf16")
     fl = NUM_STEPS * flux_flops_per_forward(4096, T5)
     par = _parity_record()
@@ -161,6 +163,12 @@ def fp8_leg(pipe, G, rank, steps=2):
                         "1024x1024, 28 steps, FLUX.1-dev shape, denoise + VAE decode + uint8/PIL",
             "whole_step_tflops_per_gpu": fl * G / (el / steps) / 1e12, "frac_of_fp8_dense_peak": fl * G / (el / steps) / 1e12 / FP8_DENSE_PEAK_TFLOPS,
             "pixel_rmse_vs_oracle": rmse("fp8"), "inside_1e-2_bar": bool(pol.get("fp8", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2),
+            "int8_all_block_linears": {"value": steps * G / el_i, "one_image_in_flight": 1.0 / single_i,
+                                       "dtype": "int8 block-GEMM operands (symmetric, per-channel weight / per-token activation scales), exact int32 accumulate "
+                                                "(v_mfma_i32_16x16x64_i8, the fp8 MFMA rate), bf16 elsewhere",
+                                       "whole_step_tflops_per_gpu": fl * G / (el_i / steps) / 1e12,
+                                       "pixel_rmse_vs_oracle": rmse("int8"),
+                                       "inside_1e-2_bar": bool(pol.get("int8", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)},
             "single_stream_blocks_only": {"value": steps * G / el_s, "one_image_in_flight": 1.0 / single_s, "fp8_gemms": ["single_in", "single_out"],
                                           "pixel_rmse_vs_oracle": rmse("fp8_single"),
                                           "inside_1e-2_bar": bool(pol.get("fp8_single", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)}}
@@ -340,7 +348,7 @@ def side_workload(a, dist, rank, world, dev):
         res = {"metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X", "value": images / elapsed, "unit": "images/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None,
-               "dtype": "bf16" if a.precision == "bf16" else FP8_DTYPE,
+               "dtype": {"bf16": "bf16", "fp8": FP8_DTYPE, "int8": INT8_DTYPE}[a.precision],
                "data": "synthetic" if not a.dry_run else "none (dry run: stub pipeline on the CPU, gloo; the rate is meaningless)",
                "config": {"workload": workload, "precision": a.precision, "images_per_rank_per_step": G if a.workload == "config2" else None,
                           "prompts": a.prompts if a.workload == "config5" else None,
@@ -363,7 +371,7 @@ def main():
     ap.add_argument("--no-trace", action="store_true", help="skip the per-launch HIP-event trace (roofline leg)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="independent images advanced concurrently per rank (engine contexts on separate streams); a step = this many images")
-    ap.add_argument("--precision", choices=("bf16", "fp8"), default=None,
+    ap.add_argument("--precision", choices=("bf16", "fp8", "int8"), default=None,
                     help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path "
                          "(the default of --workload config5)")
     ap.add_argument("--no-fp8-leg", action="store_true",
@@ -480,7 +488,8 @@ def main():
             "metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.precision == "bf16" else "fp8_e4m3 block-GEMM operands (per-channel weight / per-token activation scales), fp32 accumulate, bf16 elsewhere",
+            "dtype": {"bf16": "bf16", "fp8": "fp8_e4m3 block-GEMM operands (per-channel weight / per-token activation scales), fp32 accumulate, bf16 elsewhere",
+                      "int8": INT8_DTYPE}[a.precision],
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE config 2: ThinkDiff-CLIP single image+text, FLUX.1-dev shape (11.9 B params, seeded "
@@ -508,7 +517,7 @@ def main():
             res["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None,
-                "kernel": kern[dom] if a.precision == "bf16" else kern[dom].replace(">", ",fp8>"),
+                "kernel": kern[dom] if a.precision == "bf16" else kern[dom].replace(">", "," + a.precision + ">"),
                 "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
                 "avg_flops_per_launch": gm["flops"] / max(gm["launches"], 1),
             }
