@@ -63,30 +63,58 @@ def bench_gemmcfg():
 
 
 def bench_gemmfp8():
-    """fp8 (e4m3, v_mfma_scale 16x16x128) vs bf16 GEMM on the LN-fed FLUX shapes, cold weights (pool cycling), interleaved."""
-    for M, N, K in [(4289, 21504, 3072), (4289, 9216, 3072), (4289, 12288, 3072), (4289, 3072, 12288), (4289, 3072, 15360)]:
+    """fp8 (e4m3, v_mfma_scale 16x16x128) and int8 (v_mfma_i32_16x16x64_i8) vs bf16 GEMM on the FLUX shapes, cold weights (pool cycling),
+    interleaved; plus the sustained FLUX-step mix per operand type (3 s windows, alternating)."""
+    ops = {}
+    for name, M, N, K in [("single_in", 4289, 21504, 3072), ("qkv", 4289, 9216, 3072), ("ff1", 4289, 12288, 3072), ("attn_out", 4289, 3072, 3072),
+                          ("ff2", 4289, 3072, 12288), ("single_out", 4289, 3072, 15360)]:
         x = torch.randn(M, K, device="cuda").bfloat16()
-        npool = max(2, int(1.2e9 // (N * K * 2)))
+        npool = max(2, int(0.8e9 // (N * K * 2)))
         pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(npool)]
         qpool = [_hip.quant_rows_fp8(w) for w in pool]
+        ipool = [_hip.quant_rows_int8(w) for w in pool]
         xq, xs = _hip.quant_rows_fp8(x)
+        xi, xis = _hip.quant_rows_int8(x)
         b = torch.randn(N, device="cuda").bfloat16()
         y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         fl = 2.0 * M * N * K
         st = {"i": 0}
-        def f_bf16():
+        def f_bf16(x=x, pool=pool, b=b, y=y, st=st, npool=npool):
             st["i"] = (st["i"] + 1) % npool
             _hip.linear(x, pool[st["i"]], b, out=y)
-        def f_fp8():
+        def f_fp8(xq=xq, xs=xs, qpool=qpool, b=b, y=y, st=st, npool=npool):
             st["i"] = (st["i"] + 1) % npool
             wq, ws = qpool[st["i"]]
             _hip.linear_fp8(xq, xs, wq, ws, b, out=y)
-        best = {"bf16": 1e9, "fp8": 1e9}
+        def f_int8(xi=xi, xis=xis, ipool=ipool, b=b, y=y, st=st, npool=npool):
+            st["i"] = (st["i"] + 1) % npool
+            wq, ws = ipool[st["i"]]
+            _hip.linear_int8(xi, xis, wq, ws, b, out=y)
+        fns = {"bf16": f_bf16, "fp8": f_fp8, "int8": f_int8}
+        ops[name] = (fns, fl)
+        best = {k: 1e9 for k in fns}
         for rnd in range(4):
-            best["bf16"] = min(best["bf16"], timeit(f_bf16, iters=10, warmup=2))
-            best["fp8"] = min(best["fp8"], timeit(f_fp8, iters=10, warmup=2))
-        print(f"M={M} N={N} K={K}: bf16 {best['bf16']:7.3f} ms {fl/best['bf16']/1e9:7.1f} TF/s   fp8 {best['fp8']:7.3f} ms {fl/best['fp8']/1e9:7.1f} TF/s   x{best['bf16']/best['fp8']:.2f}", flush=True)
-        del pool, qpool
+            for k, f in fns.items():
+                best[k] = min(best[k], timeit(f, iters=10, warmup=2))
+        print(f"{name:10s} M={M} N={N} K={K}: " + "   ".join(f"{k} {best[k]:7.3f} ms {fl/best[k]/1e9:7.1f} TF/s" for k in fns) +
+              f"   fp8 x{best['bf16']/best['fp8']:.2f}  int8 x{best['bf16']/best['int8']:.2f}", flush=True)
+    seq = [("qkv", 1), ("attn_out", 1), ("ff1", 1), ("ff2", 1), ("single_in", 2), ("single_out", 2)]
+    fl_seq = sum(ops[n][1] * k for n, k in seq)
+    res = {k: [] for k in ("bf16", "fp8", "int8")}
+    for rnd in range(2):
+        for which in res:
+            def run_seq():
+                for n, k in seq:
+                    for _ in range(k):
+                        ops[n][0][which]()
+            run_seq(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); n_it = 0
+            while time.perf_counter() - t0 < 3.0:
+                for _ in range(10):
+                    run_seq()
+                torch.cuda.synchronize(); n_it += 10
+            res[which].append(fl_seq * n_it / (time.perf_counter() - t0) / 1e12)
+    print("sustained FLUX-step GEMM mix (3 s windows): " + " | ".join(f"{k} " + " ".join(f"{v:6.0f}" for v in vs) + " TF/s" for k, vs in res.items()), flush=True)
 
 
 def bench_gemmepi():
