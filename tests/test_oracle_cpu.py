@@ -124,3 +124,32 @@ def test_qwen2_live_against_transformers_if_available():
         ref = m(input_ids=ids, position_ids=pos).last_hidden_state[0]
     mine, _ = Q.text_model_hidden(sd, cfg, pos[:, 0].to(torch.int32), token_ids=ids[0])
     assert (ref - mine).abs().max() < 1e-5
+
+
+def test_oracle_8bit_switches_quantise_what_the_engine_quantises():
+    """The oracle's fp8 / int8 operand switches (the statements the engine's 8-bit modes are tested against on the GPU): both leave the
+    bf16 graph untouched when off, perturb only the block Linears when on, and int8's perturbation is smaller than e4m3's
+    (uniform step max/127 against a 3-bit mantissa: 1.1 % against 3.5 % per GEMM) -- the reason TD_PRECISION_INT8 holds the 1e-2 pixel bar where fp8 does not."""
+    from oracle import flux_ref as R
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1)
+    sd = R.init_weights(cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 36, 64, generator=g).bfloat16()
+    pe = torch.randn(1, 10, cfg.joint_attention_dim, generator=g).bfloat16()
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g).bfloat16()
+    args = (sd, cfg, lat, pe, pool, torch.tensor([0.5]).bfloat16(), R.latent_image_ids(6, 6).bfloat16(), torch.zeros(10, 3).bfloat16(), torch.tensor([3.5]))
+    with torch.no_grad():
+        base = R.transformer_forward(*args).float()
+        out = {}
+        for flag in ("FP8_BLOCK_LINEARS", "INT8_BLOCK_LINEARS"):
+            setattr(R, flag, True)
+            try:
+                out[flag] = R.transformer_forward(*args).float()
+            finally:
+                setattr(R, flag, False)
+        assert torch.equal(R.transformer_forward(*args).float(), base)
+    rel = {k: float((v - base).pow(2).mean().sqrt() / base.pow(2).mean().sqrt()) for k, v in out.items()}
+    # (on this 2-block bf16 graph the bf16 rounding floor is a third of either figure; the 3-4x gap shows at depth: tests/test_int8_gpu.py)
+    assert 0 < rel["INT8_BLOCK_LINEARS"] < 0.8 * rel["FP8_BLOCK_LINEARS"] < 5e-2, rel
+    q, s = R._quant_rows_int8(torch.tensor([[0.0, 0.0], [1.0, -3.0], [2.5, 127.0]]))
+    assert s.tolist() == [1.0, 3.0 / 127.0, 1.0] and q.tolist() == [[0.0, 0.0], [42.0, -127.0], [2.0, 127.0]]
