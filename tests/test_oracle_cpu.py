@@ -152,4 +152,4 @@ def test_oracle_8bit_switches_quantise_what_the_engine_quantises():
     # (on this 2-block bf16 graph the bf16 rounding floor is a third of either figure; the 3-4x gap shows at depth: tests/test_int8_gpu.py)
     assert 0 < rel["INT8_BLOCK_LINEARS"] < 0.8 * rel["FP8_BLOCK_LINEARS"] < 5e-2, rel
     q, s = R._quant_rows_int8(torch.tensor([[0.0, 0.0], [1.0, -3.0], [2.5, 127.0]]))
-    assert s.tolist() == [1.0, 3.0 / 127.0, 1.0] and q.tolist() == [[0.0, 0.0], [42.0, -127.0], [2.0, 127.0]]
+    assert torch.allclose(s, torch.tensor([1.0, 3.0 / 127.0, 1.0])) and q.tolist() == [[0.0, 0.0], [42.0, -127.0], [2.0, 127.0]]
