@@ -30,6 +30,7 @@ T_TXT = 193            # 65 aligner tokens + 128 T5 tokens
 GUIDANCE = 3.5
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FP8_DENSE_PEAK_TFLOPS = 5000.0
+RESULT_OUT = sys.stdout            # the stream the ONE JSON line goes to (main() re-points it at the process's original stdout)
 FP8_DTYPE = "fp8_e4m3 block-GEMM operands, fp32 accumulate, bf16 elsewhere"
 INT8_DTYPE = "int8 block-GEMM operands (symmetric W8A8), exact int32 accumulate, bf16 elsewhere"
 
@@ -356,7 +357,7 @@ def side_workload(a, dist, rank, world, dev):
                "dry_run": bool(a.dry_run)}
         if not a.dry_run:
             res["whole_step_tflops"] = fl * images / elapsed / 1e12
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=RESULT_OUT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -390,6 +391,12 @@ def main():
 
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))      # BEFORE anything touches the GPU in this process
+    # ONE line on stdout: libraries write banners there (RCCL prints its version block at communicator creation, gloo its
+    # connection notes), so this process keeps the real stdout for the result and points fd 1 at stderr for everything else.
+    global RESULT_OUT
+    sys.stdout.flush()
+    RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -539,7 +546,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             # the 1-GPU box's CPU share is 16 cores; never oversubscribe past the affinity mask
             res["cpu_baseline"] = cpu_baseline(min(len(os.sched_getaffinity(0)), 16))
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=RESULT_OUT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
