@@ -62,10 +62,10 @@ def draw_flux_weights(param_shapes, seed=WEIGHT_SEED, device="cpu"):
         yield name, t.view(*shape)
 
 
-def pipeline_inputs(T, seed, device="cpu"):
+def pipeline_inputs(T, seed, device="cpu", side=128):
     """Inputs of one job from the same generator (streams seed, seed+1, seed+2): raw latents [1,16,128,128] ~ IH4(0,1) (where the
     drivers draw randn with their seed-42 generator), T prompt-embedding rows ~ 0.1 * IH4, the pooled CLIP vector ~ IH4."""
-    raw = hash_normal(16 * 128 * 128, 0, seed, 1.0, device).view(1, 16, 128, 128)
+    raw = hash_normal(16 * side * side, 0, seed, 1.0, device).view(1, 16, side, side)
     pe = hash_normal(T * 4096, 0, seed + 1, 0.1, device).view(1, T, 4096)
     pool = hash_normal(768, 0, seed + 2, 1.0, device).view(1, 768)
     return raw, pe, pool
@@ -89,4 +89,6 @@ def draw_vae_weights(param_shapes, seed=WEIGHT_SEED + 7, device="cpu"):
     return sd
 
 
-GOLDEN_JOBS = {"cfg2_T193": dict(T=193, seed=42), "cfg5_T258": dict(T=258, seed=43)}
+# side = latent height = width (image = 8 x side): 128 = the 1024^2 of configs 2 / 5; 64 = the 512^2 the LVLM multi-image drivers render
+# (reference scripts/test/test_mllama_t5_decoder_flux_multi_image.py:258-259), T = 128 aligner tokens there
+GOLDEN_JOBS = {"cfg2_T193": dict(T=193, seed=42, side=128), "cfg5_T258": dict(T=258, seed=43, side=128), "lvlm512_T128": dict(T=128, seed=44, side=64)}

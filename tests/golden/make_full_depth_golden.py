@@ -42,7 +42,8 @@ def main(jobs):
     print(f"weights drawn in {time.time() - t0:.0f} s: {sum(t.numel() for t in sd.values()) / 1e9:.2f} B parameters, checksum {ck:#x} / vae {vck:#x}", flush=True)
     for job in jobs:
         spec = C.GOLDEN_JOBS[job]
-        raw, pe, pool = C.pipeline_inputs(spec["T"], spec["seed"])
+        side = spec["side"]
+        raw, pe, pool = C.pipeline_inputs(spec["T"], spec["seed"], side=side)
         lat = R.pack_latents(raw)
         trace, t0 = [], time.time()
 
@@ -52,9 +53,9 @@ def main(jobs):
                 print(f"  {job}: step {len(self)} / 28 at {time.time() - t0:.0f} s", flush=True)
         trace = Progress()
         with torch.no_grad():
-            out = R.denoise(sd, cfg, lat, pe, pool, 64, 64, 28, guidance_scale=3.5, trace=trace)
-            _, u8 = V.latents_to_image(vsd, vcfg, out, 128, 128)
-        fx = {"job": job, "T": spec["T"], "seed": spec["seed"], "weight_seed": C.WEIGHT_SEED, "weights_checksum": ck, "vae_checksum": vck,
+            out = R.denoise(sd, cfg, lat, pe, pool, side // 2, side // 2, 28, guidance_scale=3.5, trace=trace)
+            _, u8 = V.latents_to_image(vsd, vcfg, out, side, side)
+        fx = {"job": job, "T": spec["T"], "seed": spec["seed"], "side": side, "weight_seed": C.WEIGHT_SEED, "weights_checksum": ck, "vae_checksum": vck,
               "steps": list(C.GOLDEN_STEPS), "latents": torch.stack([trace[s - 1][0] for s in C.GOLDEN_STEPS]).contiguous(),
               "image_u8": u8[0].contiguous(), "oracle_seconds": time.time() - t0, "oracle_threads": torch.get_num_threads(),
               "torch": str(torch.__version__)}
