@@ -474,19 +474,30 @@ class QwenChatFrontend:
         merged = self.visual(feats["pixel_values"], grid).pooler_output
         merge = self.visual.merge
         counts = [t * h * w // (merge * merge) for t, h, w in grid]
-        g0 = m0 = 0
+        # One embedding gather and ONE scatter of the merged vision tokens for the whole batch: the placeholder positions are known on
+        # the host (they are token ids), so nothing here waits for the device -- a boolean-mask assignment per request would
+        # synchronise with the vision tower once per request.
+        import numpy as np
+        g0 = 0
+        all_ids, spans, grids = [], [], []
         for i, ims in zip(need, per_req):
-            r = out[i]
             g = grid[g0:g0 + len(ims)]
-            n_tok = sum(counts[g0:g0 + len(ims)])
-            ids = Qwen2VLTextEngine.expand_image_placeholders(list(r["prompt_token_ids"]), g, merge, self.image_token_id)
-            emb = self.mllama.embed_tokens(ids)
-            mask = torch.tensor(ids) == self.image_token_id
-            emb[mask.to(emb.device)] = merged[m0:m0 + n_tok]
-            r["prompt_token_ids"], r["inputs_embeds"] = ids, emb
-            r["position_ids"] = Qwen2VLTextEngine.mrope_position_ids(ids, g, merge, self.image_token_id)
+            ids = Qwen2VLTextEngine.expand_image_placeholders(list(out[i]["prompt_token_ids"]), g, merge, self.image_token_id)
+            spans.append((len(all_ids), len(all_ids) + len(ids)))
+            all_ids += ids
+            grids.append(g)
             g0 += len(ims)
-            m0 += n_tok
+        flat_ids = np.asarray(all_ids, dtype=np.int64)
+        where = np.flatnonzero(flat_ids == self.image_token_id)
+        if where.size != sum(counts):
+            raise ValueError(f"the batch holds {where.size} image placeholder tokens for {sum(counts)} merged vision tokens")
+        emb_all = self.mllama.embed_tokens(all_ids)
+        emb_all.index_copy_(0, torch.from_numpy(where).to(emb_all.device), merged.to(emb_all.dtype))
+        for i, (a0, a1), g in zip(need, spans, grids):
+            r = out[i]
+            ids = all_ids[a0:a1]
+            r["prompt_token_ids"], r["inputs_embeds"] = ids, emb_all[a0:a1]
+            r["position_ids"] = Qwen2VLTextEngine.mrope_position_ids(ids, g, merge, self.image_token_id)
         return out
 
     def _device_preprocess_plan(self):
