@@ -189,6 +189,10 @@ enum { TD_PRECISION_BF16 = 0, TD_PRECISION_FP8_E4M3 = 1,
         * rate (v_mfma_i32_16x16x64_i8, exact int32 accumulation), with a uniform step of max/127 instead of e4m3's 3-bit mantissa */
        TD_PRECISION_INT8 = 2 };
 int td_flux_set_precision(td_flux* f, int precision, void* stream);
+/* TD_PRECISION_INT8 only: source of the per-token activation scales of the MLP operands.  0 (default) = measured on the spot (one
+ * quantisation pass per tensor); 1 = the maxima the PREVIOUS denoise step accumulated for the same tensor and token x 1.25 (clip beyond):
+ * the MLP intermediate then leaves the producing GEMM epilogue as int8.  First steps and out-of-order steps use mode 0.  Parent context. */
+int td_flux_set_act_scales(td_flux* f, int mode);
 /* Which block Linears take the fp8 path while the precision is TD_PRECISION_FP8_E4M3 (default: all).  The rest run in bf16 from
  * the bf16 weights: a speed / deviation-from-bf16 trade.  Parent context only; takes effect at the next step. */
 enum { TD_FP8_QKV = 1, TD_FP8_OUT = 2, TD_FP8_FF1 = 4, TD_FP8_FF2 = 8,      /* double-stream blocks: to_q|k|v (+add_*), to_out, ff.net.0, ff.net.2 */

@@ -105,3 +105,40 @@ def test_int8_mode_matches_int8_oracle(hip):
     print(f"tiny config: hip~bf16-oracle {e16:.4f}  hip-int8~oracle-int8 {e88:.4f}  int8~bf16 hip {d_hip:.4f} oracle {d_ref:.4f}")
     assert e16 < 2e-2 and e88 < 2e-2
     assert d_hip < 3e-2 and abs(d_hip - d_ref) < 0.5 * d_ref + 2e-3
+
+
+def test_int8_history_scales_track_the_dynamic_path(hip):
+    """td_flux_set_act_scales(1): from the second denoise step on, the MLP operands are quantised inside the producing GEMM epilogue under
+    the previous step's per-token maxima x 1.25.  A 6-step tiny denoise must stay close to the per-step-measured ("dynamic") int8 path --
+    far closer than int8 is to bf16 -- and a repeated run must reproduce itself bit for bit (the history is rebuilt from step 0)."""
+    from oracle import flux_ref as R
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+    cfg = R.tiny_config(num_layers=2, num_single_layers=3)
+    sd = R.init_weights(cfg, seed=8)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=2, num_single_layers=3, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=1024, max_txt_tokens=64, max_steps=8)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    h2 = w2 = 24
+    T, n = 40, 6
+    lat = torch.randn(h2 * w2, 64, generator=g).bfloat16().cuda()
+    pe = torch.randn(T, cfg.joint_attention_dim, generator=g).bfloat16().cuda()
+    pool = torch.randn(cfg.pooled_projection_dim, generator=g).bfloat16().cuda()
+    sig = R.make_sigmas(n, h2 * w2)
+    m.set_condition(pe, pool, R.latent_image_ids(h2, w2))
+    m.set_timesteps([effective_scalar(float(s) * 1000.0, torch.bfloat16) for s in sig[:-1]], 3500.0)
+    outs = {}
+    for name, kw in (("bf16", dict(precision="bf16")), ("dynamic", dict(precision="int8")), ("history", dict(precision="int8", act_scales="history")),
+                     ("history2", dict(precision="int8", act_scales="history"))):
+        m.set_precision(**kw)
+        x = lat.clone()
+        m.denoise(x, sig)
+        torch.cuda.synchronize()
+        outs[name] = x.float().cpu()
+    m.set_precision("bf16")
+    rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    d_int8, d_hist, d_hd = rel(outs["dynamic"], outs["bf16"]), rel(outs["history"], outs["bf16"]), rel(outs["history"], outs["dynamic"])
+    print(f"6-step tiny denoise: int8 dynamic~bf16 {d_int8:.4f}  int8 history~bf16 {d_hist:.4f}  history~dynamic {d_hd:.4f}")
+    assert torch.isfinite(outs["history"]).all() and torch.equal(outs["history"], outs["history2"])
+    assert 0 < d_hd and d_hist < 1.5 * d_int8 + 1e-3

@@ -674,7 +674,7 @@ int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, floa
 
 
 // ---- per-row dynamic fp8 (OCP e4m3) quantisation: weights at load time (per output channel), activations per token ----
-__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, int int8) {
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, int int8, unsigned* amax_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x,
   amax = wave_max(amax);
   const float s = amax > 0.f ? amax * (int8 ? 1.0f / 127.0f : 1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / s;
-  if (lane == 0) scale[row] = s;
+  if (lane == 0) { scale[row] = s; if (amax_out) amax_out[row] = as_u32(amax); }
   uint8_t* qr = q + (size_t)row * ldq;
   for (int c = lane * 8; c < K; c += 512) {
     float v[8];
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x,
 
 // the same with the row held in registers between the amax pass and the conversion (K = NCH * 512 <= 16384): one read of x
 template <int NCH>
-__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int int8) {
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int int8, unsigned* amax_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t
   amax = wave_max(amax);
   const float s = amax > 0.f ? amax * (int8 ? 1.0f / 127.0f : 1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / s;
-  if (lane == 0) scale[row] = s;
+  if (lane == 0) { scale[row] = s; if (amax_out) amax_out[row] = as_u32(amax); }
   uint8_t* qr = q + (size_t)row * ldq + lane * 8;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -726,16 +726,74 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t
   }
 }
 
-int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8) {
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8, unsigned* amax_out) {
   TD_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_fp8: bad arguments");
   TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_quant_rows_fp8");
   const dim3 grid(nblk), block(256);
   switch (K % 512 == 0 ? K / 512 : 0) {
-#define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, int8); break;
+#define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, int8, amax_out); break;
     TD_CASE(1) TD_CASE(2) TD_CASE(4) TD_CASE(6) TD_CASE(8) TD_CASE(24) TD_CASE(30)
 #undef TD_CASE
-    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K, int8);
+    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K, int8, amax_out);
   }
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- int8 with scales fixed in advance (the engine's history-scaled mode) ----------------------------------------------------------------
+// q[r, :] = clamp(rint(x[r, :] * inv[r]), +-127): the columns of a row the GEMM / attention epilogues did not quantise themselves (the attention half
+// of a single-stream block's [attn | mlp] operand), under the SAME per-row scale; the row maximum of |x| joins amax[r] (atomic max on float bits).
+__global__ __launch_bounds__(256) void td_quant_rows_given_inv_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, const float* inv, unsigned* amax, int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  uint8_t* qr = q + (size_t)row * ldq;
+  const float iv = inv[row];
+  float am = 0.f;
+  for (int c = lane * 8; c < K; c += 512) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(xr + c), v);
+    unsigned w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned acc = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        am = fmaxf(am, fabsf(v[4 * h + b]));
+        acc |= ((unsigned)__float2int_rn(fminf(fmaxf(v[4 * h + b] * iv, -127.f), 127.f)) & 0xffu) << (8 * b);
+      }
+      w[h] = acc;
+    }
+    *(u32x2_t*)(qr + c) = u32x2_t{w[0], w[1]};
+  }
+  am = wave_max(am);
+  if (lane == 0) atomicMax(amax + row, as_u32(am));
+}
+
+int td_quant_rows_given_inv_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, const float* inv, unsigned* amax, int rows, int K, hipStream_t stream) {
+  TD_CHECK_ARG(x && q && inv && amax && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_given_inv: bad arguments");
+  TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_quant_rows_given_inv");
+  hipLaunchKernelGGL(td_quant_rows_given_inv_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, q, ldq, inv, amax, rows, K);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// amax bits -> this step's scale = max(amax, tiny) * margin / 127 and its inverse; the accumulators are cleared for the step being started
+__global__ void td_q8_scales_from_amax_kernel(unsigned* amax, float* scale, float* inv, long long n, float margin) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = fmaxf(as_f32(amax[i]), 1e-30f);
+  const float s = a * margin * (1.0f / 127.0f);
+  scale[i] = s;
+  inv[i] = 1.0f / s;
+  amax[i] = 0u;
+}
+
+int td_q8_scales_from_amax_launch(unsigned* amax, float* scale, float* inv, long long n, float margin, hipStream_t stream) {
+  TD_CHECK_ARG(amax && scale && inv && n > 0 && margin >= 1.0f, "td_q8_scales_from_amax: bad arguments");
+  TD_GRID_1D(nblk, n, 256, "td_q8_scales_from_amax");
+  hipLaunchKernelGGL(td_q8_scales_from_amax_kernel, dim3(nblk), dim3(256), 0, stream, amax, scale, inv, n, margin);
   TD_CHECK_LAUNCH();
   return 0;
 }

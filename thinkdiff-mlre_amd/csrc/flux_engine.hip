@@ -87,6 +87,13 @@ struct td_flux {
   int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
   std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
+  // int8 with history scales (td_flux_set_act_scales): per (block tensor, token) the scale / inverse scale of THIS step, taken from the maxima the
+  // previous step accumulated (hs_amax, float bits) -- tensors: MLP input of double block i = [i], [attn | mlp] operand of single block i = [L + i]
+  int act_scale_mode = 0;                   // parent: 0 = per-token scales measured on the spot (a pass per tensor), 1 = history
+  float *hs_scale = nullptr, *hs_inv = nullptr;
+  unsigned* hs_amax = nullptr;
+  int hs_cap = 0;                           // tokens per tensor in the three arrays
+  int hs_step = -1, hs_T = 0, hs_S = 0;     // the step (and token layout) whose maxima hs_amax holds
   // a forked context (td_flux_fork) shares the parent's weights (bf16 arena, fp8 arena, precision) and owns its
   // workspace, conditioning and schedule: several images in flight on separate streams fill each other's kernel tails
   td_flux* parent = nullptr;
@@ -163,23 +170,32 @@ int gemm2(td_flux* f, hipStream_t s, const bf16_t* A0, const bf16_t* W0, const b
 }
 
 // fp8 forms of gemm / gemm2: A is e4m3 rows + per-row scales, W an Fp8Mat
+// int8 output of the activated result under scales fixed in advance (TdGemmParams::q8)
+struct Q8Out { uint8_t* q = nullptr; int ld = 0; const float* inv = nullptr; unsigned* amax = nullptr; };
+
 int gemm8(td_flux* f, hipStream_t s, const uint8_t* A, int lda, const float* a_scale, const Fp8Mat& W, const bf16_t* b, bf16_t* C, int ldc,
           int M, int N, int K, int act = TD_ACT_NONE, const bf16_t* gate = nullptr, const bf16_t* res = nullptr, int ldr = 0,
-          bf16_t* C2 = nullptr, int ldc2 = 0, int act2 = TD_ACT_NONE, int n_split = 0) {
+          bf16_t* C2 = nullptr, int ldc2 = 0, int act2 = TD_ACT_NONE, int n_split = 0, const Q8Out* q8 = nullptr) {
   TdGemmParams p;
   const td_flux* root8 = f->parent ? f->parent : f;
   p.fp8 = root8->precision == TD_PRECISION_FP8_E4M3; p.i8 = root8->precision == TD_PRECISION_INT8;
   p.A = (const bf16_t*)A; p.lda = lda; p.a_scale = a_scale; p.W = (const bf16_t*)W.q; p.w_scale = W.s;
   p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.n_split = n_split;
+  if (q8) { p.q8 = q8->q; p.ldq8 = q8->ld; p.q8_inv = q8->inv; p.q8_amax = q8->amax; }
   const int cfg = td_gemm_config_id(M, N, K / 2);
   TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * M * N * K);
   return td_gemm_launch(p, s);
 }
 int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, const Fp8Mat& W0, const bf16_t* b0, bf16_t* C0, int M0,
             const uint8_t* A1, const float* as1, const Fp8Mat& W1, const bf16_t* b1, bf16_t* C1, int M1, int ld_a, int ld_c, int N, int K,
-            int act = TD_ACT_NONE, const bf16_t* gate0 = nullptr, const bf16_t* gate1 = nullptr, bool residual = false) {
+            int act = TD_ACT_NONE, const bf16_t* gate0 = nullptr, const bf16_t* gate1 = nullptr, bool residual = false,
+            const Q8Out* q8_0 = nullptr, const Q8Out* q8_1 = nullptr) {
   TdGemmParams p;
+  if (q8_0 && q8_1) {
+    p.q8 = q8_0->q; p.ldq8 = q8_0->ld; p.q8_inv = q8_0->inv; p.q8_amax = q8_0->amax;
+    p.g_q8 = q8_1->q; p.g_q8_inv = q8_1->inv; p.g_q8_amax = q8_1->amax;
+  }
   const td_flux* root8 = f->parent ? f->parent : f;
   p.fp8 = root8->precision == TD_PRECISION_FP8_E4M3; p.i8 = root8->precision == TD_PRECISION_INT8;
   p.A = (const bf16_t*)A0; p.a_scale = as0; p.W = (const bf16_t*)W0.q; p.w_scale = W0.s; p.bias = b0; p.C = C0; p.M = M0;
@@ -192,9 +208,9 @@ int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, cons
   return td_gemm_launch(p, s);
 }
 // per-token quantisation of a bf16 activation matrix into f->aq / f->as_
-int quant_act(td_flux* f, hipStream_t s, const bf16_t* x, int ldx, int rows, int K) {
+int quant_act(td_flux* f, hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned* amax_out = nullptr) {
   TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
-  return td_quant_rows_fp8_launch(x, ldx, f->aq, K, f->as_, rows, K, s, (f->parent ? f->parent : f)->precision == TD_PRECISION_INT8);
+  return td_quant_rows_fp8_launch(x, ldx, f->aq, K, f->as_, rows, K, s, (f->parent ? f->parent : f)->precision == TD_PRECISION_INT8, amax_out);
 }
 
 int norm_rows(td_flux* f, hipStream_t s, const TdNormParams& p) {
@@ -250,7 +266,11 @@ int alloc_workspace(td_flux* f) {
       {(void**)&f->tvals, (n + 1) * 4},
       {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
       {(void**)&f->attn_ws, (int64_t)td_attn_streamk_ws_bytes()},
+      {(void**)&f->hs_scale, (int64_t)(cfg->num_layers + cfg->num_single_layers) * S * 4}, {(void**)&f->hs_inv, (int64_t)(cfg->num_layers + cfg->num_single_layers) * S * 4},
+      {(void**)&f->hs_amax, (int64_t)(cfg->num_layers + cfg->num_single_layers) * S * 4},
   };
+  f->hs_cap = (int)S;
+  f->hs_step = -1;
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
   hipError_t e = hipMalloc((void**)&f->ws, (size_t)total);
@@ -440,6 +460,16 @@ int td_flux_set_fp8_gemms(td_flux* f, unsigned mask) {
   TD_CHECK_ARG(f && !f->parent, "td_flux_set_fp8_gemms: set it on the parent context (forks follow it)");
   TD_CHECK_ARG((mask & ~(unsigned)TD_FP8_ALL_GEMMS) == 0, "td_flux_set_fp8_gemms: unknown bits in mask 0x%x", mask);
   f->fp8_mask = mask;
+  return TD_OK;
+}
+
+// TD_PRECISION_INT8 only: where the per-token activation scales of the attention-output / MLP operands come from.  0 (default): measured
+// on the spot -- one quantisation pass per tensor.  1: from the maxima the PREVIOUS denoise step accumulated for the same tensor and
+// token, times 1.25 (values beyond that clip at +-127): the MLP intermediate then leaves the producing GEMM epilogue as int8 and the
+// passes over it disappear; the first step of an image, and any step that does not follow its predecessor, runs the mode-0 path.
+int td_flux_set_act_scales(td_flux* f, int mode) {
+  TD_CHECK_ARG(f && !f->parent && (mode == 0 || mode == 1), "td_flux_set_act_scales: parent context, mode 0 or 1");
+  f->act_scale_mode = mode;
   return TD_OK;
 }
 
@@ -634,6 +664,14 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
   const int q_int8 = root->precision == TD_PRECISION_INT8;
   // the LayerNorm ahead of an fp8 Linear writes e4m3 rows + scales, ahead of a bf16 one the bf16 rows
+  // history scales (int8): this step quantises the MLP operands under the scales the previous step's maxima give
+  const int nT = L + Ls;
+  const bool hist_mode = q_int8 && root->act_scale_mode == 1;
+  const bool use_hist = hist_mode && step > 0 && f->hs_step == step - 1 && f->hs_T == T && f->hs_S == S;
+  if (hist_mode) {
+    if (use_hist) TD_TRY(td_q8_scales_from_amax_launch(f->hs_amax, f->hs_scale, f->hs_inv, (long long)nT * f->hs_cap, 1.25f, s));
+    else TD_CHECK_HIP(hipMemsetAsync(f->hs_amax, 0, (size_t)nT * f->hs_cap * 4, s));
+  }
   auto norm_for = [&](bool fp8) {
     if (fp8) { np.q = f->xq; np.ldq = D; np.q_scale = f->xs; np.q_int8 = q_int8; } else { np.q = nullptr; np.q_scale = nullptr; }
   };
@@ -669,19 +707,28 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
     norm_for(m8 & TD_FP8_FF1);
     TD_TRY(norm_rows(f, s, np));
+    const bool ff_hist = use_hist && (m8 & TD_FP8_FF1) && (m8 & TD_FP8_FF2);
+    float* hsc = f->hs_scale + (size_t)i * f->hs_cap;
+    float* hiv = f->hs_inv + (size_t)i * f->hs_cap;
+    unsigned* ham = f->hs_amax + (size_t)i * f->hs_cap;
     if (m8 & TD_FP8_FF1) {
       const DoubleW8& w8 = root->dbl8[i];
+      Q8Out q_img, q_ctx;
+      q_img.q = f->aq + (size_t)T * M; q_img.ld = M; q_img.inv = hiv + T; q_img.amax = ham + T;
+      q_ctx.q = f->aq; q_ctx.ld = M; q_ctx.inv = hiv; q_ctx.amax = ham;
       TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.ff1_img, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
-                     f->xq, f->xs, w8.ff1_ctx, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
+                     f->xq, f->xs, w8.ff1_ctx, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH, nullptr, nullptr, false,
+                     ff_hist ? &q_img : nullptr, ff_hist ? &q_ctx : nullptr));
     } else {
       TD_TRY(gemm2(f, s, xn_img, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
                    f->xn, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
     }
     if (m8 & TD_FP8_FF2) {
       const DoubleW8& w8 = root->dbl8[i];
-      TD_TRY(quant_act(f, s, f->mlp, M, S, M));
-      TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * M, f->as_ + T, w8.ff2_img, w.ff2_img_b, h_img, Si,
-                     f->aq, f->as_, w8.ff2_ctx, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
+      if (!ff_hist) TD_TRY(quant_act(f, s, f->mlp, M, S, M, hist_mode ? ham : nullptr));
+      const float* asc = ff_hist ? hsc : f->as_;
+      TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * M, asc + T, w8.ff2_img, w.ff2_img_b, h_img, Si,
+                     f->aq, asc, w8.ff2_ctx, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
     } else {
       TD_TRY(gemm2(f, s, f->mlp + (size_t)T * M, w.ff2_img_w, w.ff2_img_b, h_img, Si,
                    f->mlp, w.ff2_ctx_w, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
@@ -695,11 +742,17 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     np.shiftA = np.shiftB = ms; np.scaleA = np.scaleB = ms + D;
     norm_for(m8 & TD_FP8_SINGLE_IN);
     TD_TRY(norm_rows(f, s, np));
+    const bool sg_hist = use_hist && fused_split && (m8 & TD_FP8_SINGLE_IN) && (m8 & TD_FP8_SINGLE_OUT);
+    float* hsc = f->hs_scale + (size_t)(L + i) * f->hs_cap;
+    float* hiv = f->hs_inv + (size_t)(L + i) * f->hs_cap;
+    unsigned* ham = f->hs_amax + (size_t)(L + i) * f->hs_cap;
     if (m8 & TD_FP8_SINGLE_IN) {
       const SingleW8& w8 = root->sgl8[i];
       if (fused_split) {
+        Q8Out q_mlp;
+        q_mlp.q = f->aq + D; q_mlp.ld = D + M; q_mlp.inv = hiv; q_mlp.amax = ham;      // the mlp half of [attn | mlp], int8, straight from the epilogue
         TD_TRY(gemm8(f, s, f->xq, D, f->xs, w8.w1, w.b1, f->qkv, 3 * D, S, 3 * D + M, D, TD_ACT_NONE, nullptr, nullptr, 0,
-                     f->cat + D, D + M, TD_ACT_GELU_TANH, 3 * D));
+                     f->cat + D, D + M, TD_ACT_GELU_TANH, 3 * D, sg_hist ? &q_mlp : nullptr));
       } else {
         Fp8Mat wa = w8.w1, wb = w8.w1;
         wb.q += (size_t)3 * D * D; wb.s += 3 * D;
@@ -721,8 +774,13 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     ap.O = f->cat; ap.ldo = D + M;
     TD_TRY(attn(f, s, ap));
     if (m8 & TD_FP8_SINGLE_OUT) {
-      TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M));
-      TD_TRY(gemm8(f, s, f->aq, D + M, f->as_, root->sgl8[i].w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
+      if (sg_hist) {      // the attention half under the same per-token scale (a fifth of the row), the mlp half is already there
+        TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
+        TD_TRY(td_quant_rows_given_inv_launch(f->cat, D + M, f->aq, D + M, hiv, ham, S, D, s));
+      } else {
+        TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M, hist_mode ? ham : nullptr));
+      }
+      TD_TRY(gemm8(f, s, f->aq, D + M, sg_hist ? hsc : f->as_, root->sgl8[i].w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
     } else {
       TD_TRY(gemm(f, s, f->cat, D + M, w.w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
     }
@@ -736,6 +794,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
   TD_TRY(norm_rows(f, s, nf));
   TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
+  if (hist_mode) { f->hs_step = step; f->hs_T = T; f->hs_S = S; } else f->hs_step = -1;
   return TD_OK;
 }
 

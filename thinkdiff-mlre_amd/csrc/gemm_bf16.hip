@@ -47,6 +47,7 @@ __device__ __forceinline__ float apply_act(float x) {
 // the problem a block works on (grouped launches carry two; see TdGemmParams)
 struct ProbView {
   const bf16_t* bias; const bf16_t* gate; const bf16_t* res; bf16_t* C; int M;
+  uint8_t* q8; const float* q8_inv; unsigned* q8_amax;      // int8 output form (TdGemmParams::q8), rows of THIS problem
 };
 
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;   // beyond any descriptor range (operands are < 4 GiB - 64 KiB, checked on the host)
@@ -58,7 +59,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 // `act` and `mode` are block-uniform run-time values: ONE body, with scalar branches around the optional stages of a row.
 // (One instantiation per activation, selected by a switch in front, made the compiler hoist the shared `acc + bias` of all
 // WM rows above the switch: 128 extra live values and a spilling kernel.)
-template <int WM, int WN>   // mode 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
+template <int WM, int WN, bool Q8 = false>   // mode 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
 __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second,
                                          const int act, const int mode) {
   constexpr int NV = 4 * WN;
@@ -70,6 +71,13 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
   const int ncols_out = second ? pp.N - pp.n_split : (pp.C2 ? pp.n_split : pp.N);
   const bool use_res = p.res != nullptr;
 
+  // Q8 (int8 kernels, 16 columns per lane): this output -- the activated one: the second of a split launch, else the only one -- leaves as
+  // symmetric int8 under a per-row scale the CALLER fixed in advance (q8_inv[m] = 1 / scale: the engine takes it from the previous denoise
+  // step), 16 bytes per lane and row, and the row maxima of what was produced go to q8_amax[m] (atomic max on the float bits: next step's
+  // scales).  The separate per-token quantisation pass over this tensor then does not exist.
+  const bool q8_here = Q8 && p.q8 != nullptr && (pp.C2 ? second : true);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(q8_here ? p.q8 : nullptr, (unsigned)((long long)(p.M - 1) * pp.ldq8 + ncols_out));
+  const __amdgpu_buffer_rsrc_t rsQi = make_rsrc(q8_here ? p.q8_inv : nullptr, (unsigned)p.M * 4u);
   const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cout, (unsigned)(((long long)(p.M - 1) * ldo + ncols_out) * 2));
   const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * pp.ldr + pp.N) * 2));
   const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.bias, (unsigned)pp.N * 2u);
@@ -141,6 +149,31 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
 #pragma unroll
           for (int c = 0; c < NV; ++c) v[c] = apply_act<TD_ACT_QUICK_GELU>(v[c]);
           break;
+      }
+    }
+    if constexpr (Q8 && NV == 16) {
+      if (q8_here) {
+        round_all();                     // the activation's output is a bf16 tensor in the reference graph
+        float am = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) am = fmaxf(am, fabsf(v[c]));
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));          // the row's maximum over this wave's 64 columns
+        const float inv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsQi, (unsigned)m * 4u, 0, 0));
+        u32x4_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          unsigned w = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int qv = __float2int_rn(fminf(fmaxf(v[4 * k + b] * inv, -127.f), 127.f));
+            w |= ((unsigned)qv & 0xffu) << (8 * b);
+          }
+          o[k] = w;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsQ, (cok[0] && cok[1]) ? (unsigned)m * (unsigned)pp.ldq8 + (unsigned)ncol : OOB_OFFSET, 0, 0);
+        if ((threadIdx.x & 48) == 0 && m < p.M) __hip_atomic_fetch_max(p.q8_amax + m, as_u32(am), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
       }
     }
     if (mode == 1) {
@@ -265,6 +298,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   pv.res = second_prob ? p.g_res : p.res;
   pv.C = second_prob ? p.g_C : p.C;
   pv.M = second_prob ? p.g_M : p.M;
+  pv.q8 = second_prob ? p.g_q8 : p.q8; pv.q8_inv = second_prob ? p.g_q8_inv : p.q8_inv; pv.q8_amax = second_prob ? p.g_q8_amax : p.q8_amax;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
@@ -547,7 +581,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
     return;
   }
   const int mode = act != TD_ACT_NONE ? 0 : (pv.gate ? 1 : (pv.res ? 2 : 0));
-  epilogue<WM, WN>(p, pv, acc, mbeg, nbeg, second, act, mode);
+  epilogue<WM, WN, I8 && WN == 4>(p, pv, acc, mbeg, nbeg, second, act, mode);
 #endif
 }
 
@@ -630,6 +664,13 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   }
   if (p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
+  if (p.q8) {
+    TD_CHECK_ARG(p.i8 && p.q8_inv && p.q8_amax && p.ldq8 % 16 == 0 && ((uintptr_t)p.q8) % 16 == 0 && (p.g_M == 0 || (p.g_q8 && p.g_q8_inv && p.g_q8_amax)),
+                 "td_gemm(q8 output): int8 kernels only; needs the per-row inverse scales, the amax accumulators and 16-byte aligned rows");
+    TD_CHECK_ARG((p.C2 ? (p.N - p.n_split) % 16 == 0 && p.n_split % 16 == 0 : p.N % 16 == 0) && (long long)(p.M + p.g_M + 288) * p.ldq8 < (1ll << 32) - (1ll << 16),
+                 "td_gemm(q8 output): output widths must be multiples of 16");
+    TD_CHECK_ARG(cfg != 3, "td_gemm(q8 output): the 288x192 tile owns 12 columns per lane; use tile 0 or 2");
+  }
   if (p.i8) {
     TD_CHECK_ARG(p.a_scale && p.w_scale && (p.g_M == 0 || (p.g_a_scale && p.g_w_scale)) && p.conv_H == 0 && !p.out_f32,
                  "td_gemm(int8): row / column dequantisation scales are required; no conv / fp32-out form");

@@ -35,6 +35,11 @@ struct TdGemmParams {
   // int8 operands (i8 = 1): A and W hold symmetric int8 (lda, K in elements = bytes), v_mfma_i32_16x16x64_i8, exact int32 accumulation;
   // y = float(acc) * a_scale[m] * w_scale[n] -- the same scale arrays and the same 2x-bf16 MFMA rate as the fp8 form
   int i8 = 0;
+  // int8 OUTPUT of the activated result (int8 kernels, 256-wide tiles): q8[m, :] = clamp(rint(y * q8_inv[m]), +-127) with the caller's
+  // per-row inverse scales, the maxima of |y| per row accumulated into q8_amax[m] (atomic max on float bits); with a split output
+  // (C2) it applies to the second one, the first stays bf16.  g_* = the second problem of a grouped launch.  See the epilogue.
+  uint8_t* q8 = nullptr; int ldq8 = 0; const float* q8_inv = nullptr; unsigned* q8_amax = nullptr;
+  uint8_t* g_q8 = nullptr; const float* g_q8_inv = nullptr; unsigned* g_q8_amax = nullptr;
   const float* a_scale = nullptr; const float* w_scale = nullptr;        // [M], [N]
   const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
@@ -97,7 +102,10 @@ struct TdNormParams {
 };
 // per-row dynamic fp8 quantisation of a bf16 matrix: q[r,:] = e4m3(x[r,:] / s_r), s_r = max|x[r,:]| / 448 (1 for a zero row)
 // int8 = 1: symmetric int8 instead (q = rint(x / s_r), s_r = max|x[r,:]| / 127)
-int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8 = 0);
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8 = 0, unsigned* amax_out = nullptr);
+// history-scaled int8 (csrc/elementwise.hip, bottom): quantise under GIVEN inverse scales; turn accumulated maxima into the next scales
+int td_quant_rows_given_inv_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, const float* inv, unsigned* amax, int rows, int K, hipStream_t stream);
+int td_q8_scales_from_amax_launch(unsigned* amax, float* scale, float* inv, long long n, float margin, hipStream_t stream);
 int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream);
 
 struct TdQkRopeParams {

@@ -59,6 +59,7 @@ def _declare(L):
         "td_flux_init_random": [vp, ctypes.c_uint64, f32, vp],
         "td_flux_set_precision": [vp, i32, vp],
         "td_flux_set_fp8_gemms": [vp, ctypes.c_uint],
+        "td_flux_set_act_scales": [vp, i32],
         "td_flux_fork": [vp, vp],
         "td_flux_denoise_multi": [vp, vp, i32, vp, i32, vp],
         "td_flux_set_condition": [vp, vp, i32, vp, vp, vp, i32, vp],

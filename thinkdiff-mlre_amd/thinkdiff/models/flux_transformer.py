@@ -148,7 +148,7 @@ class FluxTransformer2DModel:
 
     FP8_GEMMS = {"qkv": 1, "out": 2, "ff1": 4, "ff2": 8, "single_in": 16, "single_out": 32}     # TD_FP8_* of include/thinkdiff_hip.h
 
-    def set_precision(self, precision: str = "bf16", fp8_gemms=None):
+    def set_precision(self, precision: str = "bf16", fp8_gemms=None, act_scales: str = "dynamic"):
         """"bf16" (default) or "fp8": e4m3 operands for the block GEMMs (weights quantised per output channel from the
         parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly).
         fp8_gemms: None = every block Linear, or the classes that take the fp8 path (names of FP8_GEMMS, or the bit mask);
@@ -157,7 +157,9 @@ class FluxTransformer2DModel:
         _hip.check(self._L.td_flux_set_precision(self._h, code, _hip.stream_ptr()))
         mask = 63 if fp8_gemms is None else (int(fp8_gemms) if isinstance(fp8_gemms, int) else sum(self.FP8_GEMMS[str(n)] for n in fp8_gemms))
         _hip.check(self._L.td_flux_set_fp8_gemms(self._h, mask))
-        self.precision, self.fp8_gemms = ("bf16", "fp8", "int8")[code], mask
+        # int8 only: "history" = per-token scales of the MLP operands from the previous denoise step (td_flux_set_act_scales)
+        _hip.check(self._L.td_flux_set_act_scales(self._h, {"dynamic": 0, "history": 1}[act_scales] if code == 2 else 0))
+        self.precision, self.fp8_gemms, self.act_scales = ("bf16", "fp8", "int8")[code], mask, (act_scales if code == 2 else "dynamic")
         return self
 
     # ---- conditioning / schedule ----------------------------------------------------------------------
