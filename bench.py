@@ -320,7 +320,7 @@ def side_workload(a, dist, rank, world, dev):
     else:
         from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
         pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=512, max_steps=32)
-        pipe.transformer.set_precision(a.precision)
+        pipe.transformer.set_precision(a.precision, act_scales=a.act_scales if a.precision == "int8" else "dynamic")
         pipe.images_in_flight = max(1, a.in_flight)
     G = max(1, a.in_flight)
     if a.workload == "config5":
@@ -381,6 +381,8 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp8", "int8"), default=None,
                     help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path "
                          "(the default of --workload config5)")
+    ap.add_argument("--act-scales", choices=("dynamic", "history"), default="dynamic",
+                    help="--precision int8 only: per-token activation scales measured on the spot, or taken from the previous denoise step (td_flux_set_act_scales)")
     ap.add_argument("--no-fp8-leg", action="store_true",
                     help="skip the short fp8 measurement of BASELINE config 5's shape that the default bf16 run appends as the `fp8` sub-object")
     ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
@@ -433,7 +435,7 @@ def main():
     from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
     pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=512, max_steps=32)
     tr = pipe.transformer
-    tr.set_precision(a.precision)
+    tr.set_precision(a.precision, act_scales=a.act_scales if a.precision == "int8" else "dynamic")
 
     # synthetic inputs (SURVEY.md 8d cfg 2), seed + rank as the reference drivers do
     g = torch.Generator().manual_seed(42 + rank)
