@@ -196,7 +196,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 
   const float inv = 1.0f / (RS ? lacc[0] : half_swap_sum(lacc[0]));
   const int q = q0 + l31;
-  attn_store_rows(o, inv, Ob + (size_t)min(q, Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < Sq);
+  bool stored = false;
+  if constexpr (!CAUSAL && !BIAS && !VARLEN) {      // the int8 output form exists for the joint attention only (keeps it out of the other streams)
+    if (p.q8) {
+      const int qr = min(q, Sq - 1);
+      attn_store_rows_q8(o, inv, p.q8 + (size_t)qr * p.ldq8 + head * D, h5, p.q8_inv[qr], p.q8_amax + qr, q < Sq);
+      stored = true;
+    }
+  }
+  if (!stored) attn_store_rows(o, inv, Ob + (size_t)min(q, Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < Sq);
 #endif
 }
 
@@ -435,7 +443,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     // ---- normalise and store: lane holds O[q][db*32 + (r&3) + 8 (r>>2) + 4 h5] ------------------------------------------
     const float inv = 1.0f / l_run;
     const int q = q0 + l31;
-    attn_store_rows(o, inv, p.O + (size_t)batch * p.o_bstride + (size_t)min(q, p.Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < p.Sq);
+    if (p.q8) {
+      const int qr = min(q, p.Sq - 1);
+      attn_store_rows_q8(o, inv, p.q8 + (size_t)qr * p.ldq8 + head * D, h5, p.q8_inv[qr], p.q8_amax + qr, q < p.Sq);
+    } else {
+      attn_store_rows(o, inv, p.O + (size_t)batch * p.o_bstride + (size_t)min(q, p.Sq - 1) * p.ldo + head * D, h5, (p.ldo & 7) == 0 && !(p.variant & 0x200), q < p.Sq);
+    }
   }
 #endif
 }
@@ -516,6 +529,8 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
   if (p.kv_lens) TD_CHECK_ARG(p.causal && !p.bias, "td_attention: per-sequence kv lengths exist for the causal kernel only");
   if (p.q_prescaled) TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts, "td_attention: pre-scaled q is a form of the joint (unmasked) attention only");
+  if (p.q8) TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts && p.batch == 1 && p.q8_inv && p.q8_amax && p.ldq8 % 8 == 0 && ((uintptr_t)p.q8) % 8 == 0,
+                         "td_attention: the int8 output form is for the joint attention of one batch entry, with 8-byte aligned rows");
   if (p.seg_starts) {   // packed segments: plain grid over (query tiles of the longest segment, heads, segments)
     TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && p.Sq == p.Skv, "td_attention(varlen): full attention inside each segment only (no mask, bias or cache lengths)");
     static std::atomic<unsigned long long> a6{0};

@@ -200,6 +200,35 @@ __device__ __forceinline__ void attn_store_rows(const f32x16_t (&o)[4], const fl
   }
 }
 
+// The same tile as symmetric int8 under a per-row scale fixed in advance (the FLUX engine's history-scaled int8 mode: the attention output
+// is the A operand of the next int8 GEMM): q = clamp(rint(bf16(o * inv) * qinv), +-127), 8 contiguous bytes per lane after the same pairwise
+// lane exchange, and the row-head maximum of |bf16(o * inv)| joins amax (atomic max on the float bits; lanes of the lower half only).
+__device__ __forceinline__ void attn_store_rows_q8(const f32x16_t (&o)[4], const float inv, uint8_t* row_ptr, const int h5, const float qinv, unsigned* amax,
+                                                   const bool live) {
+  float am = 0.f;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      unsigned w[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned acc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float v = rbf(o[db][4 * (g + h) + b] * inv);          // the attention output is a bf16 tensor in the reference graph
+          am = fmaxf(am, fabsf(v));
+          acc |= ((unsigned)__float2int_rn(fminf(fmaxf(v * qinv, -127.f), 127.f)) & 0xffu) << (8 * b);
+        }
+        w[h] = acc;
+      }
+      const auto r = __builtin_amdgcn_permlane32_swap(w[0], w[1], false, false);
+      if (live) *(u32x2_t*)(row_ptr + db * 32 + 8 * (g + h5)) = u32x2_t{r[0], r[1]};
+    }
+  am = half_swap_max(am);
+  if (live && h5 == 0) __hip_atomic_fetch_max(amax, as_u32(am), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 namespace {

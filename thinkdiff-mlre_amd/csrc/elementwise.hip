@@ -741,44 +741,6 @@ int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, floa
 }
 
 // ---- int8 with scales fixed in advance (the engine's history-scaled mode) ----------------------------------------------------------------
-// q[r, :] = clamp(rint(x[r, :] * inv[r]), +-127): the columns of a row the GEMM / attention epilogues did not quantise themselves (the attention half
-// of a single-stream block's [attn | mlp] operand), under the SAME per-row scale; the row maximum of |x| joins amax[r] (atomic max on float bits).
-__global__ __launch_bounds__(256) void td_quant_rows_given_inv_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, const float* inv, unsigned* amax, int rows, int K) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bf16_t* xr = x + (size_t)row * ldx;
-  uint8_t* qr = q + (size_t)row * ldq;
-  const float iv = inv[row];
-  float am = 0.f;
-  for (int c = lane * 8; c < K; c += 512) {
-    float v[8];
-    unpack8(*(const u32x4_t*)(xr + c), v);
-    unsigned w[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      unsigned acc = 0;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        am = fmaxf(am, fabsf(v[4 * h + b]));
-        acc |= ((unsigned)__float2int_rn(fminf(fmaxf(v[4 * h + b] * iv, -127.f), 127.f)) & 0xffu) << (8 * b);
-      }
-      w[h] = acc;
-    }
-    *(u32x2_t*)(qr + c) = u32x2_t{w[0], w[1]};
-  }
-  am = wave_max(am);
-  if (lane == 0) atomicMax(amax + row, as_u32(am));
-}
-
-int td_quant_rows_given_inv_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, const float* inv, unsigned* amax, int rows, int K, hipStream_t stream) {
-  TD_CHECK_ARG(x && q && inv && amax && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_given_inv: bad arguments");
-  TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_quant_rows_given_inv");
-  hipLaunchKernelGGL(td_quant_rows_given_inv_kernel, dim3(nblk), dim3(256), 0, stream, x, ldx, q, ldq, inv, amax, rows, K);
-  TD_CHECK_LAUNCH();
-  return 0;
-}
-
 // amax bits -> this step's scale = max(amax, tiny) * margin / 127 and its inverse; the accumulators are cleared for the step being started
 __global__ void td_q8_scales_from_amax_kernel(unsigned* amax, float* scale, float* inv, long long n, float margin) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

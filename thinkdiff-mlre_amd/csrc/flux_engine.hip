@@ -88,7 +88,8 @@ struct td_flux {
   std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
   // int8 with history scales (td_flux_set_act_scales): per (block tensor, token) the scale / inverse scale of THIS step, taken from the maxima the
-  // previous step accumulated (hs_amax, float bits) -- tensors: MLP input of double block i = [i], [attn | mlp] operand of single block i = [L + i]
+  // previous step accumulated (hs_amax, float bits) -- tensors: MLP input of double block i = [i], [attn | mlp] operand of single block i = [L + i],
+  // attention output of double block i = [L + Ls + i]
   int act_scale_mode = 0;                   // parent: 0 = per-token scales measured on the spot (a pass per tensor), 1 = history
   float *hs_scale = nullptr, *hs_inv = nullptr;
   unsigned* hs_amax = nullptr;
@@ -266,8 +267,8 @@ int alloc_workspace(td_flux* f) {
       {(void**)&f->tvals, (n + 1) * 4},
       {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
       {(void**)&f->attn_ws, (int64_t)td_attn_streamk_ws_bytes()},
-      {(void**)&f->hs_scale, (int64_t)(cfg->num_layers + cfg->num_single_layers) * S * 4}, {(void**)&f->hs_inv, (int64_t)(cfg->num_layers + cfg->num_single_layers) * S * 4},
-      {(void**)&f->hs_amax, (int64_t)(cfg->num_layers + cfg->num_single_layers) * S * 4},
+      {(void**)&f->hs_scale, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4}, {(void**)&f->hs_inv, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4},
+      {(void**)&f->hs_amax, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4},
   };
   f->hs_cap = (int)S;
   f->hs_step = -1;
@@ -665,7 +666,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const int q_int8 = root->precision == TD_PRECISION_INT8;
   // the LayerNorm ahead of an fp8 Linear writes e4m3 rows + scales, ahead of a bf16 one the bf16 rows
   // history scales (int8): this step quantises the MLP operands under the scales the previous step's maxima give
-  const int nT = L + Ls;
+  const int nT = 2 * L + Ls;
   const bool hist_mode = q_int8 && root->act_scale_mode == 1;
   const bool use_hist = hist_mode && step > 0 && f->hs_step == step - 1 && f->hs_T == T && f->hs_S == S;
   if (hist_mode) {
@@ -694,12 +695,19 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     rp.wqA = w.norm_added_q; rp.wkA = w.norm_added_k; rp.wqB = w.norm_q; rp.wkB = w.norm_k;
     TD_TRY(qk_rope(f, s, rp));
     ap.O = f->attn; ap.ldo = D;
+    // history scales: the attention epilogue writes its output as int8 under the previous step's per-token scale (the out-proj's A operand)
+    const bool ao_hist = use_hist && (m8 & TD_FP8_OUT);
+    float* asc_o = f->hs_scale + (size_t)(L + Ls + i) * f->hs_cap;
+    unsigned* aam_o = f->hs_amax + (size_t)(L + Ls + i) * f->hs_cap;
+    if (ao_hist) { ap.q8 = f->aq; ap.ldq8 = D; ap.q8_inv = f->hs_inv + (size_t)(L + Ls + i) * f->hs_cap; ap.q8_amax = aam_o; }
     TD_TRY(attn(f, s, ap));
+    ap.q8 = nullptr;
     if (m8 & TD_FP8_OUT) {
       const DoubleW8& w8 = root->dbl8[i];
-      TD_TRY(quant_act(f, s, f->attn, D, S, D));
-      TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * D, f->as_ + T, w8.out_img, w.out_img_b, h_img, Si,
-                     f->aq, f->as_, w8.out_ctx, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
+      if (!ao_hist) TD_TRY(quant_act(f, s, f->attn, D, S, D, hist_mode ? aam_o : nullptr));
+      const float* asc = ao_hist ? asc_o : f->as_;
+      TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * D, asc + T, w8.out_img, w.out_img_b, h_img, Si,
+                     f->aq, asc, w8.out_ctx, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
     } else {
       TD_TRY(gemm2(f, s, f->attn + (size_t)T * D, w.out_img_w, w.out_img_b, h_img, Si,
                    f->attn, w.out_ctx_w, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
@@ -772,11 +780,12 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     rp.wqA = rp.wqB = w.norm_q; rp.wkA = rp.wkB = w.norm_k;
     TD_TRY(qk_rope(f, s, rp));
     ap.O = f->cat; ap.ldo = D + M;
+    if (sg_hist) { ap.q8 = f->aq; ap.ldq8 = D + M; ap.q8_inv = hiv; ap.q8_amax = ham; }   // the attention half of [attn | mlp] as int8, same per-token scale
     TD_TRY(attn(f, s, ap));
+    ap.q8 = nullptr;
     if (m8 & TD_FP8_SINGLE_OUT) {
-      if (sg_hist) {      // the attention half under the same per-token scale (a fifth of the row), the mlp half is already there
-        TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
-        TD_TRY(td_quant_rows_given_inv_launch(f->cat, D + M, f->aq, D + M, hiv, ham, S, D, s));
+      if (sg_hist) {
+        // both halves of the operand are in f->aq already: the mlp half from the W1 epilogue, the attention half from the attention epilogue
       } else {
         TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M, hist_mode ? ham : nullptr));
       }

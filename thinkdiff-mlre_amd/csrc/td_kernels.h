@@ -79,6 +79,9 @@ struct TdAttnParams {
   // q already carries scale * log2(e) (folded in where q was last rounded to bf16: TdQkRopeParams::q_premul), so scores arrive in
   // the exp2 domain and `scale` is not applied again; joint (non-causal, no bias / lengths / segments) attention only
   int q_prescaled = 0;
+  // int8 output instead of O (joint attention; the FLUX engine's history-scaled int8 mode): q8[b][row, head*128 + d] = clamp(rint(o * q8_inv[row]), +-127)
+  // with the caller's per-row inverse scales, row maxima of |o| accumulated into q8_amax[row] (atomic max on float bits).  ldq8 in bytes.
+  uint8_t* q8 = nullptr; int ldq8 = 0; const float* q8_inv = nullptr; unsigned* q8_amax = nullptr;
 };
 size_t td_attn_streamk_ws_bytes();
 
@@ -103,8 +106,7 @@ struct TdNormParams {
 // per-row dynamic fp8 quantisation of a bf16 matrix: q[r,:] = e4m3(x[r,:] / s_r), s_r = max|x[r,:]| / 448 (1 for a zero row)
 // int8 = 1: symmetric int8 instead (q = rint(x / s_r), s_r = max|x[r,:]| / 127)
 int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8 = 0, unsigned* amax_out = nullptr);
-// history-scaled int8 (csrc/elementwise.hip, bottom): quantise under GIVEN inverse scales; turn accumulated maxima into the next scales
-int td_quant_rows_given_inv_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, const float* inv, unsigned* amax, int rows, int K, hipStream_t stream);
+// history-scaled int8 (csrc/elementwise.hip, bottom): turn the accumulated maxima into the next step's scales
 int td_q8_scales_from_amax_launch(unsigned* amax, float* scale, float* inv, long long n, float margin, hipStream_t stream);
 int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream);
 
