@@ -88,6 +88,15 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
  * DEVICE int32[n_seg + 1]; max_len = the longest segment (sizes the grid).  One launch for all segments, no mask across them. */
 int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
                              const int* seg_starts, int n_seg, int max_len, int Hq, int Hkv, float scale, void* stream);
+/* The joint (unmasked, one batch entry, Hq == Hkv) attention with BOTH products on the block-scaled e4m3 matrix instruction
+ * (csrc/attention_fp8.hip): the same bf16 q / k / v / o and strides as td_attention_bf16; q, k, v are packed to e4m3 under
+ * power-of-two scales (q, k per (token, head); v per (64-key tile, head)) in one pass into `workspace`
+ * (td_attention_fp8_workspace_bytes(Sq, Skv, Hq) bytes, 16-byte aligned, contents undefined afterwards), the probabilities
+ * are rounded to e4m3, accumulation and the softmax state stay fp32.  An option of the 8-bit modes (the reference graph has no
+ * such path): its error is ~5 % of an attention output on random operands, see DESIGN.md section 4 for what it does to an image. */
+size_t td_attention_fp8_workspace_bytes(int Sq, int Skv, int Hq);
+int td_attention_fp8(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
+                     int Sq, int Skv, int Hq, float scale, void* workspace, void* stream);
 /* Selects the kernel structure td_attention_bf16 launches: 0 = shipped (joint attention with more (query tile, head) items
  * than CUs runs as one round of persistent workgroups over equal KV-tile ranges; the first such call on a device allocates a
  * 35 MB hand-off workspace, so make it before capturing into a hipGraph), 1 = one workgroup per item for every shape, 2 = the
@@ -193,6 +202,10 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream);
  * quantisation pass per tensor); 1 = the maxima the PREVIOUS denoise step accumulated for the same tensor and token x 1.25 (clip beyond):
  * the MLP intermediate then leaves the producing GEMM epilogue as int8.  First steps and out-of-order steps use mode 0.  Parent context. */
 int td_flux_set_act_scales(td_flux* f, int mode);
+/* Arithmetic of the joint attention in every block: TD_ATTENTION_BF16 (default: the reference graph's) or TD_ATTENTION_FP8 (QK^T and P.V
+ * on the e4m3 matrix instruction, td_attention_fp8).  Independent of td_flux_set_precision; meant for the 8-bit modes.  Parent context. */
+enum { TD_ATTENTION_BF16 = 0, TD_ATTENTION_FP8 = 1 };
+int td_flux_set_attention(td_flux* f, int mode);
 /* Which block Linears take the fp8 path while the precision is TD_PRECISION_FP8_E4M3 (default: all).  The rest run in bf16 from
  * the bf16 weights: a speed / deviation-from-bf16 trade.  Parent context only; takes effect at the next step. */
 enum { TD_FP8_QKV = 1, TD_FP8_OUT = 2, TD_FP8_FF1 = 4, TD_FP8_FF2 = 8,      /* double-stream blocks: to_q|k|v (+add_*), to_out, ff.net.0, ff.net.2 */

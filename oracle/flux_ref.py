@@ -116,7 +116,7 @@ def init_weights(cfg: FluxConfig, seed: int = 0, std: float = 0.02, dtype=torch.
 def timestep_proj(t: torch.Tensor) -> torch.Tensor:
     """[ext] embeddings.get_timestep_embedding(256, flip_sin_to_cos=True, downscale_freq_shift=0)."""
     half = 128
-    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     emb = t[:, None].float() * torch.exp(exponent)[None, :]
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
@@ -126,7 +126,7 @@ def rope_tables(ids: torch.Tensor, axes_dims=(16, 56, 56), theta: float = 10000.
     pos = ids.double()
     cos_out, sin_out = [], []
     for i, d in enumerate(axes_dims):
-        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=ids.device)[: d // 2] / d))
         ang = torch.outer(pos[:, i], freqs)
         cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
         sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
@@ -211,7 +211,54 @@ def _heads(x, H):
     return x.view(B, S, H, -1).transpose(1, 2)
 
 
+# 8-bit attention mode (restates csrc/attention_fp8.hip, the attention of td_flux_set_attention(TD_ATTENTION_FP8)): q (times
+# scale x log2 e), k and v go to OCP e4m3 under power-of-two (E8M0) scales -- q and k per (token, head), v per (64-key tile,
+# head) -- the scores accumulate exactly, P = exp2(s - ceil(rowmax) + 7) is rounded to e4m3 (an integer reference: the rounding of a
+# probability does not depend on how the kernel tiles the keys), the row sum is taken over the rounded P,
+# O = P.V accumulates exactly.  Off by default: the reference has no such path.
+# The probabilities: "linear" (the shipped kernel) -- the e4m3 BYTE is rne(8 (s - ceil(rowmax)) + 112) clamped to [0, 126], i.e.
+# 2^floor(x) (1 + frac(x)) with 3 mantissa bits instead of 2^x (an e4m3 byte read as an integer is a piecewise-linear log2 scale);
+# "exp2" -- P = exp2(s - ceil(rowmax) + 7) rounded to e4m3 (the kernel's A/B form).
+FP8_ATTENTION = False
+FP8_ATTENTION_PROB = "linear"
+
+
+def _e8m0_quant(x, dims):
+    """x -> (e4m3 payload as float, power-of-two scale): the smallest 2^e (|e| <= 40) with amax / 2^e <= 448 over `dims`
+    (integer logic on the fp32 bits of amax * fp32(1/448), as the pack kernel does it)."""
+    amax = x.abs().amax(dim=dims, keepdim=True)
+    m, ex = torch.frexp(amax * (1.0 / 448.0))                  # r = m 2^ex, m in [0.5, 1)
+    e = torch.where(m == 0.5, ex - 1, ex).clamp_(-40, 40)
+    e = torch.where(amax == 0, torch.full_like(e, -40), e)
+    s = torch.exp2(e.float())
+    return (x / s).to(torch.float8_e4m3fn).float(), s
+
+
+def _attention_fp8(q, k, v):
+    B, H, S, hd = q.shape
+    c = (hd ** -0.5) * math.log2(math.e)
+    out = torch.empty(B, S, H * hd, dtype=q.dtype, device=q.device)
+    pad = (-S) % 64
+    for b in range(B):
+        for h in range(H):
+            q8, sq = _e8m0_quant(q[b, h].float() * c, (1,))
+            k8, sk = _e8m0_quant(k[b, h].float(), (1,))
+            vg = F.pad(v[b, h].float(), (0, 0, 0, pad)).view(-1, 64, hd)
+            v8, sv = _e8m0_quant(vg, (1, 2))
+            vq = (v8 * sv).view(-1, hd)[:S]
+            s = (q8 * sq) @ (k8 * sk).T
+            ref = torch.ceil(s.amax(dim=1, keepdim=True))
+            if FP8_ATTENTION_PROB == "linear":
+                p = torch.round(8.0 * (s - ref) + 112.0).clamp_(0, 126).to(torch.uint8).view(torch.float8_e4m3fn).float()
+            else:
+                p = torch.exp2(s - ref + 7.0).to(torch.float8_e4m3fn).float()
+            out[b, :, h * hd:(h + 1) * hd] = ((p @ vq) / p.sum(dim=1, keepdim=True)).to(q.dtype)
+    return out
+
+
 def _attention(q, k, v):
+    if FP8_ATTENTION:
+        return _attention_fp8(q, k, v)
     o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
     B, H, S, hd = o.shape
     return o.transpose(1, 2).reshape(B, S, H * hd)
@@ -352,10 +399,11 @@ def denoise(sd, cfg: FluxConfig, latents_packed, prompt_embeds, pooled, h2, w2, 
     dt = latents_packed.dtype
     B, S, _ = latents_packed.shape
     sig = make_sigmas(num_steps, S)
-    timesteps = torch.from_numpy(sig[:-1]) * 1000.0
-    img_ids = latent_image_ids(h2, w2).to(dt)
-    txt_ids = torch.zeros(prompt_embeds.shape[1], 3).to(dt)
-    guidance = torch.full([1], guidance_scale, dtype=torch.float32).expand(B) if cfg.guidance_embeds else None
+    dev = latents_packed.device
+    timesteps = (torch.from_numpy(sig[:-1]) * 1000.0).to(dev)
+    img_ids = latent_image_ids(h2, w2).to(dt).to(dev)
+    txt_ids = torch.zeros(prompt_embeds.shape[1], 3).to(dt).to(dev)
+    guidance = torch.full([1], guidance_scale, dtype=torch.float32, device=dev).expand(B) if cfg.guidance_embeds else None
     x = latents_packed
     for i in range(num_steps):
         t = timesteps[i].expand(B).to(dt)

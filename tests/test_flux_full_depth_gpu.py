@@ -147,8 +147,10 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
     lat = R.pack_latents(raw.cpu()).cuda()
     tr = pipe.transformer
     res = {}
-    for prec, gemms in (("bf16", None), ("fp8", None), ("fp8_single", ["single_in", "single_out"]), ("int8", None), ("int8_history", None)):
-        tr.set_precision(prec.split("_")[0], fp8_gemms=gemms, act_scales="history" if prec.endswith("_history") else "dynamic")
+    for prec, gemms in (("bf16", None), ("fp8", None), ("fp8_single", ["single_in", "single_out"]), ("int8", None), ("int8_history", None),
+                        ("bf16_attn8", None), ("int8_history_attn8", None)):
+        tr.set_precision(prec.split("_")[0], fp8_gemms=gemms, act_scales="history" if "_history" in prec else "dynamic")
+        tr.set_attention("fp8" if prec.endswith("_attn8") else "bf16")
         out = pipe(prompt_embeds=pe, pooled_prompt_embeds=pool, height=1024, width=1024, num_inference_steps=28, guidance_scale=3.5,
                    latents=lat, output_type="latent").images[0].clone()
         u8 = pipe.vae.decode_packed(out, 128, 128, output_type="np").clone()
@@ -156,11 +158,12 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
         assert torch.isfinite(out.float()).all()
         res[prec] = {"latent_rel_rmse_vs_oracle": _rel_rmse(out, fx["latents"][-1]), "pixel_rmse_vs_oracle": _px_rmse(u8, fx["image_u8"]), "u8": u8}
     tr.set_precision("bf16")
-    for k in ("fp8", "fp8_single", "int8", "int8_history"):
+    tr.set_attention("bf16")
+    for k in ("fp8", "fp8_single", "int8", "int8_history", "bf16_attn8", "int8_history_attn8"):
         res[k]["pixel_rmse_vs_hip_bf16"] = _px_rmse(res[k]["u8"], res["bf16"]["u8"])
     for k, v in res.items():
         v.pop("u8")
-        print(f"[full depth] {k:10s} 28 steps, T=258: " + ", ".join(f"{a} {b:.5f}" for a, b in v.items()))
+        print(f"[full depth] {k:18s} 28 steps, T=258: " + ", ".join(f"{a} {b:.5f}" for a, b in v.items()))
     _record("fp8_policies_vs_oracle_cfg5_T258", res)
     # the ordering that must hold whatever the absolute level: more fp8 Linears -> further from the oracle
     assert res["bf16"]["pixel_rmse_vs_oracle"] <= res["fp8_single"]["pixel_rmse_vs_oracle"] <= res["fp8"]["pixel_rmse_vs_oracle"]
@@ -169,6 +172,9 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
     assert res["int8"]["pixel_rmse_vs_oracle"] < 1e-2, f"int8 pixels {res['int8']['pixel_rmse_vs_oracle']:.4f} from the oracle fixture exceed the 1e-2 bar"
     # ... also with the MLP operands quantised in the producing epilogues under the previous step's per-token scales (td_flux_set_act_scales)
     assert res["int8_history"]["pixel_rmse_vs_oracle"] < 1e-2, f"int8 (history scales) pixels {res['int8_history']['pixel_rmse_vs_oracle']:.4f} exceed the 1e-2 bar"
+    # ... and with the joint attention on the e4m3 MFMA as well (td_flux_set_attention): alone on the bf16 Linears, and under the whole 8-bit path
+    assert res["bf16_attn8"]["pixel_rmse_vs_oracle"] < 1e-2, f"bf16 Linears + e4m3 attention: pixels {res['bf16_attn8']['pixel_rmse_vs_oracle']:.4f} exceed the 1e-2 bar"
+    assert res["int8_history_attn8"]["pixel_rmse_vs_oracle"] < 1e-2, f"int8 (history) + e4m3 attention: pixels {res['int8_history_attn8']['pixel_rmse_vs_oracle']:.4f} exceed the 1e-2 bar"
 
 
 def test_full_width_block_pair_config5_shape(hip):

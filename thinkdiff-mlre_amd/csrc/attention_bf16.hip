@@ -500,6 +500,17 @@ int set_lds_attr_once(K kernel, int bytes, std::atomic<unsigned long long>& done
 
 }  // namespace
 
+// shared with attention_fp8.hip
+int td_attn_device_cus(int dev) { return device_cus(dev); }
+int td_attn_pooled_workspace(int dev, int ranges, hipStream_t stream, char** out) { return sk_pooled_workspace(dev, ranges, stream, out); }
+int td_attn_set_lds_attr(const void* kernel, int bytes, std::atomic<unsigned long long>& done, int dev) {
+  if (!((done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+    TD_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+  }
+  return 0;
+}
+
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.head_dim == D, "td_attention: head_dim=%d unsupported (only 128)", p.head_dim);
   TD_CHECK_ARG(p.Sq > 0 && p.Skv > 0 && p.Hq > 0 && p.Hkv > 0 && p.batch > 0, "td_attention: empty problem");

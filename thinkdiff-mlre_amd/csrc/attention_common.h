@@ -231,6 +231,8 @@ __device__ __forceinline__ void attn_store_rows_q8(const f32x16_t (&o)[4], const
 
 }  // namespace
 
+int td_attn_set_lds_attr(const void* kernel, int bytes, std::atomic<unsigned long long>& done, int dev);
+
 namespace {
 constexpr int SK_SLOT_FLOATS = 8 * 64 * 68;          // per boundary and side: 8 waves x 64 lanes x (64 O + m + l + 2 pad) floats
 constexpr int SK_HEADER_BYTES = 4096;                 // cnt[j] at word 16 + j

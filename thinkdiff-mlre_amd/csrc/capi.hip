@@ -96,6 +96,17 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
   return td_attn_launch(p, (hipStream_t)stream);
 }
 
+size_t td_attention_fp8_workspace_bytes(int Sq, int Skv, int Hq) { return Sq > 0 && Skv > 0 && Hq > 0 ? td_attn_fp8_ws_bytes(Sq, Skv, Hq) : 0; }
+
+int td_attention_fp8(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
+                     int Sq, int Skv, int Hq, float scale, void* workspace, void* stream) {
+  TdAttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o;
+  p.batch = 1; p.Sq = Sq; p.Skv = Skv; p.Hq = Hq; p.Hkv = Hq; p.head_dim = 128;
+  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo; p.scale = scale; p.f8_ws = workspace; p.variant = ((g_attn_variant & 1) ? 0x1000 : 0) | ((g_attn_variant & 2) ? 0x2000 : 0);      // td_attention_set_variant bit 0: the 4-wave A/B form, bit 1: exp2 probabilities
+  return td_attn_fp8_launch(p, (hipStream_t)stream);
+}
+
 int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
                              const int* seg_starts, int n_seg, int max_len, int Hq, int Hkv, float scale, void* stream) {
   TD_CHECK_ARG(seg_starts && n_seg > 0 && max_len > 0, "td_attention_varlen: empty segment list");

@@ -85,6 +85,8 @@ struct td_flux {
   uint8_t *xq = nullptr, *aq = nullptr;     // per-context, part of the workspace
   char* attn_ws = nullptr;                  // hand-off workspace of the persistent attention kernel (per context: contexts run concurrently)
   int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
+  int attn_mode = 0;                        // parent: TD_ATTENTION_BF16 / TD_ATTENTION_FP8 (td_flux_set_attention)
+  char* attn8_ws = nullptr;                 // packed e4m3 q | k | v^T of the 8-bit attention (per context)
   std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
   // int8 with history scales (td_flux_set_act_scales): per (block tensor, token) the scale / inverse scale of THIS step, taken from the maxima the
@@ -224,6 +226,13 @@ int qk_rope(td_flux* f, hipStream_t s, const TdQkRopeParams& p) {
 }
 int attn(td_flux* f, hipStream_t s, const TdAttnParams& p) {
   TraceScope ts(f, s, TD_TRACE_ATTN, 4.0 * p.Sq * (double)p.Skv * p.Hq * 128.0);
+  const td_flux* root = f->parent ? f->parent : f;
+  if (root->attn_mode == TD_ATTENTION_FP8) {      // both products on the e4m3 MFMA: pack pass + persistent kernel (csrc/attention_fp8.hip)
+    TdAttnParams q = p;
+    q.f8_ws = f->attn8_ws;
+    q.variant = p.variant & 0x1000;
+    return td_attn_fp8_launch(q, s);
+  }
   return td_attn_launch(p, s);
 }
 
@@ -267,6 +276,7 @@ int alloc_workspace(td_flux* f) {
       {(void**)&f->tvals, (n + 1) * 4},
       {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
       {(void**)&f->attn_ws, (int64_t)td_attn_streamk_ws_bytes()},
+      {(void**)&f->attn8_ws, (int64_t)td_attn_fp8_ws_bytes((int)S, (int)S, cfg->num_heads)},
       {(void**)&f->hs_scale, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4}, {(void**)&f->hs_inv, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4},
       {(void**)&f->hs_amax, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4},
   };
@@ -471,6 +481,15 @@ int td_flux_set_fp8_gemms(td_flux* f, unsigned mask) {
 int td_flux_set_act_scales(td_flux* f, int mode) {
   TD_CHECK_ARG(f && !f->parent && (mode == 0 || mode == 1), "td_flux_set_act_scales: parent context, mode 0 or 1");
   f->act_scale_mode = mode;
+  return TD_OK;
+}
+
+// The joint attention of every block: TD_ATTENTION_BF16 (default, the reference graph's arithmetic) or TD_ATTENTION_FP8 -- QK^T and P.V on
+// the e4m3 matrix instruction (csrc/attention_fp8.hip).  Independent of td_flux_set_precision; meant for the 8-bit modes, where the
+// attention is otherwise a quarter of the image.
+int td_flux_set_attention(td_flux* f, int mode) {
+  TD_CHECK_ARG(f && !f->parent && (mode == TD_ATTENTION_BF16 || mode == TD_ATTENTION_FP8), "td_flux_set_attention: parent context, TD_ATTENTION_BF16 or TD_ATTENTION_FP8");
+  f->attn_mode = mode;
   return TD_OK;
 }
 

@@ -82,8 +82,15 @@ struct TdAttnParams {
   // int8 output instead of O (joint attention; the FLUX engine's history-scaled int8 mode): q8[b][row, head*128 + d] = clamp(rint(o * q8_inv[row]), +-127)
   // with the caller's per-row inverse scales, row maxima of |o| accumulated into q8_amax[row] (atomic max on float bits).  ldq8 in bytes.
   uint8_t* q8 = nullptr; int ldq8 = 0; const float* q8_inv = nullptr; unsigned* q8_amax = nullptr;
+  // td_attn_fp8_launch only: td_attn_fp8_ws_bytes(Sq, Skv, Hq) bytes of scratch for the packed e4m3 operands
+  void* f8_ws = nullptr;
 };
 size_t td_attn_streamk_ws_bytes();
+int td_attn_device_cus(int dev);
+int td_attn_pooled_workspace(int dev, int ranges, hipStream_t stream, char** out);
+// csrc/attention_fp8.hip: the joint attention with QK^T and P.V on the e4m3 MFMA (bf16 operands in, packed on the way)
+size_t td_attn_fp8_ws_bytes(int Sq, int Skv, int H);
+int td_attn_fp8_launch(const TdAttnParams& p, hipStream_t stream);
 
 int td_attn_launch(const TdAttnParams& p, hipStream_t stream);
 // Sq = 1 (KV-cached decode) form, csrc/attention_decode.hip; td_attn_launch routes to it

@@ -60,6 +60,7 @@ def _declare(L):
         "td_flux_set_precision": [vp, i32, vp],
         "td_flux_set_fp8_gemms": [vp, ctypes.c_uint],
         "td_flux_set_act_scales": [vp, i32],
+        "td_flux_set_attention": [vp, i32],
         "td_flux_fork": [vp, vp],
         "td_flux_denoise_multi": [vp, vp, i32, vp, i32, vp],
         "td_flux_set_condition": [vp, vp, i32, vp, vp, vp, i32, vp],
@@ -117,6 +118,7 @@ def _declare(L):
         "td_silu_mul_bf16": [vp, vp, i32, i32, vp],
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
+        "td_attention_fp8": [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, f32, vp, vp],
         "td_sample_top_p_bf16": [vp, i64, i32, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, vp, vp],
     }
     for name, args in sig.items():
@@ -191,6 +193,26 @@ def attention(q, k, v, out, Hq, Hkv, scale=None, causal=False):
     check(lib().td_attention_bf16(ptr(q), q.stride(1), q.stride(0), ptr(k), ptr(v), k.stride(1), k.stride(0),
                                   ptr(out), out.stride(1), out.stride(0), B, Sq, Skv, Hq, Hkv, 128,
                                   float(scale), int(causal), stream_ptr()))
+    return out
+
+
+def attention_fp8(q, k, v, out, H, scale=None, workspace=None):
+    """Joint attention on the e4m3 MFMA: q, k, v, out [S, >= H*128] bf16 views (one batch entry); returns out.
+    `workspace`: optional uint8 tensor of td_attention_fp8_workspace_bytes (tests read the packed operands back from it)."""
+    assert q.dim() == 2 and k.dim() == 2 and v.dim() == 2 and out.dim() == 2
+    for t in (q, k, v, out):
+        assert t.dtype == torch.bfloat16 and t.stride(1) == 1
+    assert k.stride() == v.stride()
+    Sq, Skv = q.shape[0], k.shape[0]
+    if scale is None:
+        scale = 128 ** -0.5
+    L = lib()
+    L.td_attention_fp8_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = int(L.td_attention_fp8_workspace_bytes(Sq, Skv, H))
+    ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    assert ws.dtype == torch.uint8 and ws.numel() >= nbytes and ws.is_contiguous()
+    check(L.td_attention_fp8(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), Sq, Skv, H,
+                             float(scale), ptr(ws), stream_ptr()))
     return out
 
 

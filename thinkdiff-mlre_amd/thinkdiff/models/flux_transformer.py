@@ -148,6 +148,13 @@ class FluxTransformer2DModel:
 
     FP8_GEMMS = {"qkv": 1, "out": 2, "ff1": 4, "ff2": 8, "single_in": 16, "single_out": 32}     # TD_FP8_* of include/thinkdiff_hip.h
 
+    def set_attention(self, mode: str = "bf16"):
+        """Arithmetic of the joint attention: "bf16" (default, the reference graph's) or "fp8" (QK^T and P.V on the e4m3 matrix
+        instruction, td_flux_set_attention(TD_ATTENTION_FP8)); independent of set_precision, meant for the 8-bit modes."""
+        _hip.check(self._L.td_flux_set_attention(self._h, {"bf16": 0, "fp8": 1}[mode]))
+        self.attention = mode
+        return self
+
     def set_precision(self, precision: str = "bf16", fp8_gemms=None, act_scales: str = "dynamic"):
         """"bf16" (default) or "fp8": e4m3 operands for the block GEMMs (weights quantised per output channel from the
         parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly).

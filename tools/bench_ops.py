@@ -276,6 +276,36 @@ def bench_attn():
         print(f"attn S={S} H={H}: " + "   ".join(f"{names[v]} {best[v]*1e3:6.1f} us {fl/best[v]/1e9:6.0f} TF/s" for v in names), flush=True)
 
 
+def bench_attn8():
+    """The 8-bit joint attention (pack + attention kernels together) against the shipped bf16 kernel, interleaved, cold inputs."""
+    for S, H in [(4289, 24), (4354, 24)]:
+        W = H * 128
+        pool = [torch.randn(S, 3 * W, device="cuda").bfloat16() for _ in range(6)]
+        out = torch.empty(S, W, device="cuda", dtype=torch.bfloat16)
+        L = _hip.lib()
+        L.td_attention_fp8_workspace_bytes.restype = __import__("ctypes").c_size_t
+        ws = torch.empty(int(L.td_attention_fp8_workspace_bytes(S, S, H)), dtype=torch.uint8, device="cuda")
+        st = {"i": 0}
+        def f16():
+            st["i"] = (st["i"] + 1) % len(pool)
+            q = pool[st["i"]][None]
+            _hip.attention(q[:, :, :W], q[:, :, W:2 * W], q[:, :, 2 * W:], out[None], H, H)
+        def f8():
+            st["i"] = (st["i"] + 1) % len(pool)
+            q = pool[st["i"]]
+            _hip.attention_fp8(q[:, :W], q[:, W:2 * W], q[:, 2 * W:], out, H, workspace=ws)
+        best = {"bf16": 1e9, "fp8": 1e9, "fp8-4wave": 1e9, "fp8-exp2": 1e9, "fp8-4wave-exp2": 1e9}
+        for _ in range(5):
+            best["bf16"] = min(best["bf16"], timeit(f16, iters=10, warmup=2))
+            best["fp8"] = min(best["fp8"], timeit(f8, iters=10, warmup=2))
+            for var, name in ((1, "fp8-4wave"), (2, "fp8-exp2"), (3, "fp8-4wave-exp2")):
+                L.td_attention_set_variant(var)
+                best[name] = min(best[name], timeit(f8, iters=10, warmup=2))
+            L.td_attention_set_variant(0)
+        fl = 4.0 * S * S * H * 128
+        print(f"attn8 S={S} H={H}: " + "   ".join(f"{k} {v*1e3:6.1f} us {fl/v/1e9:6.0f} TF/s" for k, v in best.items()), flush=True)
+
+
 def bench_gemmref():
     """External yardstick for the block GEMMs (measurement only; never in the product): torch.nn.functional.linear (= hipBLASLt on
     this image) against td_linear on the six FLUX.1-dev block shapes at the joint sequence length, random operands, same box, same
