@@ -127,8 +127,9 @@ def fp8_leg(pipe, G, rank, steps=2):
         return pipe(prompt_embeds=pe[:n], pooled_prompt_embeds=pooled[:n], num_images_per_prompt=1, height=HEIGHT, width=WIDTH,
                     num_inference_steps=NUM_STEPS, guidance_scale=GUIDANCE, latents=packed[:n], output_type="pil").images
 
-    def measure(fp8_gemms, precision="fp8", act_scales="dynamic"):
+    def measure(fp8_gemms, precision="fp8", act_scales="dynamic", attention="bf16"):
         tr.set_precision(precision, fp8_gemms=fp8_gemms, act_scales=act_scales)
+        tr.set_attention(attention)
         run(G)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -149,7 +150,9 @@ def fp8_leg(pipe, G, rank, steps=2):
     el_s, single_s = measure(["single_in", "single_out"])          # the 38 single-stream blocks in fp8, the 19 double-stream ones in bf16
     el_i, single_i = measure(None, "int8")                         # every block Linear on symmetric int8 operands (TD_PRECISION_INT8)
     el_h, single_h = measure(None, "int8", "history")              # ... the MLP operands quantised in the producing epilogues (previous step's scales)
+    el_a, single_a = measure(None, "int8", "history", "fp8")       # ... and QK^T / P.V of the joint attention on the e4m3 MFMA (td_flux_set_attention)
     tr.set_precision("bf16")
+    tr.set_attention("bf16")
     fl = NUM_STEPS * flux_flops_per_forward(4096, T5)
     par = _parity_record()
     pol = par.get("fp8_policies_vs_oracle_cfg5_T258", {})
@@ -175,7 +178,14 @@ def fp8_leg(pipe, G, rank, steps=2):
                                                           "what": "td_flux_set_act_scales(1): per-token scales of the MLP operands from the previous denoise step x 1.25, "
                                                                   "int8 written by the producing GEMM epilogues (no quantisation pass over them)",
                                                           "pixel_rmse_vs_oracle": rmse("int8_history"),
-                                                          "inside_1e-2_bar": bool(pol.get("int8_history", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)}},
+                                                          "inside_1e-2_bar": bool(pol.get("int8_history", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)},
+                                       "history_scales_fp8_attention": {
+                                           "value": steps * G / el_a, "one_image_in_flight": 1.0 / single_a,
+                                           "what": "the line above + td_flux_set_attention(TD_ATTENTION_FP8): QK^T and P.V of every joint attention on "
+                                                   "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 q / k / v under power-of-two scales, csrc/attention_fp8.hip)",
+                                           "whole_step_tflops_per_gpu": fl * G / (el_a / steps) / 1e12,
+                                           "pixel_rmse_vs_oracle": rmse("int8_history_attn8"),
+                                           "inside_1e-2_bar": bool(pol.get("int8_history_attn8", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)}},
             "single_stream_blocks_only": {"value": steps * G / el_s, "one_image_in_flight": 1.0 / single_s, "fp8_gemms": ["single_in", "single_out"],
                                           "pixel_rmse_vs_oracle": rmse("fp8_single"),
                                           "inside_1e-2_bar": bool(pol.get("fp8_single", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)}}
@@ -321,6 +331,7 @@ def side_workload(a, dist, rank, world, dev):
         from thinkdiff.models.flux_prompt import FluxPipelineRewritePrompt
         pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=512, max_steps=32)
         pipe.transformer.set_precision(a.precision, act_scales=a.act_scales if a.precision == "int8" else "dynamic")
+        pipe.transformer.set_attention(a.attention)
         pipe.images_in_flight = max(1, a.in_flight)
     G = max(1, a.in_flight)
     if a.workload == "config5":
@@ -383,6 +394,9 @@ def main():
                          "(the default of --workload config5)")
     ap.add_argument("--act-scales", choices=("dynamic", "history"), default="dynamic",
                     help="--precision int8 only: per-token activation scales measured on the spot, or taken from the previous denoise step (td_flux_set_act_scales)")
+    ap.add_argument("--attention", choices=("bf16", "fp8"), default="bf16",
+                    help="arithmetic of the joint attention: bf16 = the reference graph's (headline), fp8 = QK^T / P.V on the e4m3 MFMA "
+                         "(td_flux_set_attention; meant for the 8-bit precisions)")
     ap.add_argument("--no-fp8-leg", action="store_true",
                     help="skip the short fp8 measurement of BASELINE config 5's shape that the default bf16 run appends as the `fp8` sub-object")
     ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
@@ -436,6 +450,7 @@ def main():
     pipe = FluxPipelineRewritePrompt.from_random(seed=1234, max_img_tokens=4096, max_txt_tokens=512, max_steps=32)
     tr = pipe.transformer
     tr.set_precision(a.precision, act_scales=a.act_scales if a.precision == "int8" else "dynamic")
+    tr.set_attention(a.attention)
 
     # synthetic inputs (SURVEY.md 8d cfg 2), seed + rank as the reference drivers do
     g = torch.Generator().manual_seed(42 + rank)
@@ -513,7 +528,8 @@ def main():
                              "advanced concurrently on separate streams over one set of weights), each from HBM-resident prompt_embeds/pooled/latents through the 28-step "
                              "denoise loop, VAE decode (FLUX.1-dev VAE shape, seeded random init) and uint8 conversion to a host "
                              "PIL image -- the reference driver's diffusion_pipe(...).images[0]"),
-                "precision": a.precision, "images_per_rank_per_step": G, "parallelism": f"dp{world} (independent images, seed+rank)",
+                "precision": a.precision, "attention": a.attention, "images_per_rank_per_step": G,
+                "parallelism": f"dp{world} (independent images, seed+rank)",
                 "algorithmic_pflop_per_image": flops_img / 1e15,
                 "weights_note": ("all 11.9 B parameters drawn N(0, 0.02).  Lines recorded before this note existed (round 1: 0.703, round 2 up to "
                                  "0.736) ran with every block weight at zero -- a truncated fill launch -- which let the chip clock ~20 % higher; "
@@ -547,7 +563,8 @@ def main():
             at = cats["attention"]
             res["attention_tflops"] = at["flops"] / (at["ms"] * 1e-3) / 1e12 if at["ms"] > 0 else 0.0
             res["attention_roofline"] = {"bound": "mfma", "achieved": res["attention_tflops"], "peak": peak, "unit": "TFLOP/s",
-                                         "frac": res["attention_tflops"] / peak, "kernel": "td_attn_fwd_d128_streamk_kernel<8,true,true>",
+                                         "frac": res["attention_tflops"] / peak,
+                                         "kernel": "td_attn_fwd_d128_streamk_kernel<8,true,true>" if a.attention == "bf16" else "td_attn_fp8_pack_kernel + td_attn_fwd_d128_fp8_kernel<8,true,true>",
                                          "launches": at["launches"], "avg_launch_us": at["ms"] * 1e3 / max(at["launches"], 1)}
         if world == 1 and a.precision == "bf16" and not a.no_fp8_leg:
             res["fp8"] = fp8_leg(pipe, G, rank)

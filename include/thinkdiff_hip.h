@@ -97,6 +97,14 @@ int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const vo
 size_t td_attention_fp8_workspace_bytes(int Sq, int Skv, int Hq);
 int td_attention_fp8(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
                      int Sq, int Skv, int Hq, float scale, void* workspace, void* stream);
+/* The same attention fed from the RAW fused projection buffer: the pack pass applies the per-head QK-RMSNorm (weights may be NULL) and the
+ * interleaved-pair rotary embedding of td_qk_norm_rope_bf16(rotate_half = 0) on its way to e4m3 -- bit-identical to calling that kernel
+ * and then td_attention_fp8, minus one HBM round trip over q | k; qkv is left unmodified.  Replaces, in the 8-bit attention mode, [ext] diffusers FluxAttnProcessor2_0: attn.norm_q / norm_k (+ norm_added_*) ->
+ * apply_rotary_emb -> F.scaled_dot_product_attention.  qkv [S, ld] bf16 with q / k / v head blocks at columns q_col / k_col / v_col; cos,
+ * sin fp32 [S,128]; rows < split take (wqA, wkA), the rest (wqB, wkB). */
+int td_attention_fp8_qk_rope(const void* qkv, int64_t ld, int q_col, int k_col, int v_col, void* o, int64_t ldo, int S, int H,
+                             const float* cos, const float* sin, int split, const void* wqA, const void* wkA, const void* wqB, const void* wkB,
+                             float eps, float scale, void* workspace, void* stream);
 /* Selects the kernel structure td_attention_bf16 launches: 0 = shipped (joint attention with more (query tile, head) items
  * than CUs runs as one round of persistent workgroups over equal KV-tile ranges; the first such call on a device allocates a
  * 35 MB hand-off workspace, so make it before capturing into a hipGraph), 1 = one workgroup per item for every shape, 2 = the

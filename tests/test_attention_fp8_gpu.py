@@ -164,6 +164,72 @@ def test_fp8_attention_more_items_than_cus(hip, S, H):
     assert _rel(out2, out) < 2e-3        # (the merge order of a split item is fixed; which owner rounds last is not)
 
 
+@pytest.mark.parametrize("S,H,split", [(64, 1, 0), (300, 2, 40), (449, 4, 449), (1000, 3, 193)])
+def test_fused_qk_norm_rope_pack_is_bit_identical(hip, S, H, split):
+    """td_attention_fp8_qk_rope (QK-RMSNorm + RoPE inside the pack pass, raw projections in) against td_qk_norm_rope_bf16 followed by
+    td_attention_fp8: the same packed bytes and scale bytes in the workspace, the same output, and an untouched projection buffer."""
+    g = torch.Generator().manual_seed(S * 3 + H)
+    D = H * 128
+    qkv = (torch.randn(S, 3 * D, generator=g) * torch.linspace(0.1, 4.0, 3 * D)[None, :]).bfloat16().cuda()
+    ids = (torch.arange(S)[:, None] * torch.tensor([0.0, 1.0, 3.0])).float().contiguous().cuda()      # a distinct angle set per token
+    cos, sin = hip.flux_rope_table(ids)
+    w = [(1.0 + 0.2 * torch.randn(128, generator=g)).bfloat16().cuda() for _ in range(4)]
+    L = _layout(S, S, H)
+    # two passes
+    a = qkv.clone()
+    hip.qk_norm_rope(a, H, H, 0, D, cos, sin, split=split, wqA=w[0], wkA=w[1], wqB=w[2], wkB=w[3])
+    ws_a = torch.zeros(L["total"], dtype=torch.uint8, device="cuda")
+    out_a = torch.zeros(S, D, dtype=torch.bfloat16, device="cuda")
+    hip.attention_fp8(a[:, :D], a[:, D:2 * D], a[:, 2 * D:], out_a, H, workspace=ws_a)
+    # one pass
+    b = qkv.clone()
+    ws_b = torch.zeros(L["total"], dtype=torch.uint8, device="cuda")
+    out_b = torch.zeros(S, D, dtype=torch.bfloat16, device="cuda")
+    hip.attention_fp8_qk_rope(b, out_b, H, cos, sin, split=split, wqA=w[0], wkA=w[1], wqB=w[2], wkB=w[3], workspace=ws_b)
+    torch.cuda.synchronize()
+    assert torch.equal(b, qkv), "the fused form must leave the projections alone"
+    assert not torch.equal(a, qkv)
+    for name, n in (("q8", S * D), ("qs", S * H), ("k8", H * L["nt"] * 8192), ("ks", H * L["nt"] * 64), ("v8", H * L["nt"] * 8192), ("vs", H * L["nt"])):
+        assert torch.equal(ws_a[L[name]:L[name] + n], ws_b[L[name]:L[name] + n]), f"packed {name} differs"
+    assert torch.equal(out_a, out_b)
+    # no norm weights: RoPE only
+    a = qkv.clone()
+    hip.qk_norm_rope(a, H, H, 0, D, cos, sin)
+    hip.attention_fp8(a[:, :D], a[:, D:2 * D], a[:, 2 * D:], out_a, H, workspace=ws_a)
+    hip.attention_fp8_qk_rope(b, out_b, H, cos, sin, workspace=ws_b)
+    torch.cuda.synchronize()
+    assert torch.equal(ws_a[:L["vs"]], ws_b[:L["vs"]]) and torch.equal(out_a, out_b)
+
+
+def test_engine_fused_rope_is_bit_identical(hip, monkeypatch):
+    """The engine in 8-bit attention mode skips td_qk_norm_rope and lets the pack pass do it (q pre-multiplied by scale x log2 e in
+    front of its one bf16 rounding on both paths): same bits as the two-pass form (TD_ATTN8_NO_FUSE)."""
+    if _PROB["form"] != "linear":
+        pytest.skip("the engine runs the shipped (integer-conversion) form only")
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig
+    cfg = R.tiny_config(num_layers=2, num_single_layers=2)
+    sd = R.init_weights(cfg, seed=8)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=2, num_single_layers=2, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(10)
+    h2, w2, T = 10, 14, 37
+    lat = torch.randn(1, h2 * w2, 64, generator=g).bfloat16().cuda()
+    pe = torch.randn(1, T, cfg.joint_attention_dim, generator=g).bfloat16().cuda()
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g).bfloat16().cuda()
+    img_ids, txt_ids = R.latent_image_ids(h2, w2), torch.zeros(T, 3)
+    t, gd = torch.tensor([0.41]).bfloat16().cuda(), torch.tensor([3.5])
+    m.set_attention("fp8")
+    fused = m.forward(lat, pe, pool, t, img_ids, txt_ids, gd)[0].clone()
+    monkeypatch.setenv("TD_ATTN8_NO_FUSE", "1")
+    two_pass = m.forward(lat, pe, pool, t, img_ids, txt_ids, gd)[0].clone()
+    monkeypatch.delenv("TD_ATTN8_NO_FUSE")
+    m.set_attention("bf16")
+    torch.cuda.synchronize()
+    assert torch.isfinite(fused.float()).all() and torch.equal(fused, two_pass)
+
+
 def test_engine_fp8_attention_matches_the_oracle_switch(hip):
     """td_flux_set_attention(TD_ATTENTION_FP8) on a tiny config (two double + two single blocks, one forward): the engine against
     oracle/flux_ref.py with FP8_ATTENTION -- as close as the bf16 engine is to the bf16 oracle -- and the distance between the two

@@ -28,6 +28,7 @@
 //     tiling and the order of arrival were (the oracle's restatement uses ceil(row maximum) - 7 and agrees to fp32 rounding).
 // Numerics: tests/test_attention_fp8_gpu.py (against oracle/flux_ref.py's restatement, FP8_ATTENTION) and the 28-step fixtures.
 #include "attention_common.h"
+#include "qk_rope_math.h"
 
 namespace {
 
@@ -84,6 +85,50 @@ __device__ __forceinline__ void load_row32(const bf16_t* p, bool live, float (&x
   }
 }
 
+// QK-RMSNorm + rotary embedding of td_qk_norm_rope_kernel on this thread's 32 elements of a head row (quarter qt of the row; the four
+// threads of a row are lanes 4r .. 4r+3): group g of 8 elements is what lane 4 qt + g of that kernel's 16-lane row owns, and the sum of
+// squares is added in its order -- the xor-butterfly 8, 4, 2, 1 over the 16 partial sums (8 and 4 cross threads: xor 2 and 1 here; 2
+// and 1 are this thread's own groups) -- so both kernels round the same numbers.  Output: the bf16-rounded values, as floats.
+__device__ __forceinline__ void norm_rope_32(float (&x)[32], const bf16_t* w, const int qt, const float eps, const float (&cs)[32], const float (&sn)[32], const float premul) {
+  float g[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[a][i] = x[8 * a + i];
+  if (w) {
+    float sq[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sq[a] = qk_sumsq8(g[a]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sq[a] += __shfl_xor(sq[a], 2);      // lanes l, l ^ 8
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sq[a] += __shfl_xor(sq[a], 1);      // ... ^ 4
+    const float s2a = sq[0] + sq[2], s2b = sq[1] + sq[3];            // ... ^ 2
+    const float rstd = qk_rstd(s2a + s2b, eps);                      // ... ^ 1
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float wv[8];
+      const u32x4_t wr = *(const u32x4_t*)(w + qt * 32 + 8 * a);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wv[2 * j] = bf_lo(wr[j]); wv[2 * j + 1] = bf_hi(wr[j]); }
+      qk_norm8(g[a], rstd, wv);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float c8[8], s8[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c8[i] = cs[8 * a + i]; s8[i] = sn[8 * a + i]; }
+    qk_rope_pairs8(g[a], c8, s8, y);
+    if (premul != 1.0f) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] *= premul;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[8 * a + i] = rbf(y[i]);
+  }
+}
+
 }  // namespace
 
 // One workgroup per (64-token tile, head): thread (row = tid / 4, quarter = tid % 4) owns 32 of a token's 128 head dims.
@@ -97,9 +142,25 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
   const int H = p.Hq;
   float x[32];
   unsigned w[8];
+  // fused QK-RMSNorm + RoPE (p.rope_cos): this token's table row, shared by its q and k (Sq == Skv)
+  const bool rope = p.rope_cos != nullptr;
+  float cs[32], sn[32];
+  if (rope && tok < p.Sq) {
+    const float* cr = p.rope_cos + (size_t)tok * D + qt * 32;
+    const float* sr = p.rope_sin + (size_t)tok * D + qt * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      const f32x4_t c4 = *(const f32x4_t*)(cr + i);
+      const f32x4_t s4 = *(const f32x4_t*)(sr + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { cs[i + j] = c4[j]; sn[i + j] = s4[j]; }
+    }
+  }
+  const bool partB = tok >= p.rope_split;
 
   if (tok < p.Sq) {      // ---- q: row-major, scale per (token, head)
     load_row32(p.Q + (size_t)tok * p.ldq + head * D + qt * 32, true, x);
+    if (rope) norm_rope_32(x, partB ? p.rope_wqB : p.rope_wqA, qt, p.rope_eps, cs, sn, p.rope_q_premul);
     float am = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) { x[i] *= qmul; am = fmaxf(am, fabsf(x[i])); }
@@ -117,6 +178,7 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
   const size_t tile = (size_t)head * nt + t;
   {                      // ---- k: the swizzled LDS image of the tile, scale per (key, head); rows past Skv are zero
     load_row32(p.K + (size_t)(live ? tok : 0) * p.ldkv + head * D + qt * 32, live, x);
+    if (rope && live) norm_rope_32(x, partB ? p.rope_wkB : p.rope_wkA, qt, p.rope_eps, cs, sn, 1.0f);      // (live is uniform over a row's four threads)
     float am = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) am = fmaxf(am, fabsf(x[i]));
@@ -489,6 +551,8 @@ int td_attn_fp8_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts, "td_attention_fp8: joint (unmasked) attention only");
   TD_CHECK_ARG(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "td_attention_fp8: row strides must be 16-byte multiples");
   TD_CHECK_ARG(((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O | (uintptr_t)p.f8_ws) % 16 == 0 && p.f8_ws, "td_attention_fp8: pointers must be 16-byte aligned, workspace present");
+  if (p.rope_cos) TD_CHECK_ARG(p.rope_sin && p.Sq == p.Skv && ((uintptr_t)p.rope_cos | (uintptr_t)p.rope_sin | (uintptr_t)p.rope_wqA | (uintptr_t)p.rope_wkA | (uintptr_t)p.rope_wqB | (uintptr_t)p.rope_wkB) % 16 == 0,
+                               "td_attention_fp8: fused QK-norm + RoPE needs both tables, Sq == Skv and 16-byte aligned tables / weights");
   if (p.q8) TD_CHECK_ARG(p.q8_inv && p.q8_amax && p.ldq8 % 8 == 0 && ((uintptr_t)p.q8) % 8 == 0, "td_attention_fp8: int8 output needs scales, maxima and 8-byte aligned rows");
   const int nt = (p.Skv + KV_TILE - 1) / KV_TILE;
   const F8Layout lay = f8_layout(p.Sq, p.Skv, p.Hq);

@@ -107,6 +107,21 @@ int td_attention_fp8(const void* q, int64_t ldq, const void* k, const void* v, i
   return td_attn_fp8_launch(p, (hipStream_t)stream);
 }
 
+int td_attention_fp8_qk_rope(const void* qkv, int64_t ld, int q_col, int k_col, int v_col, void* o, int64_t ldo, int S, int H,
+                             const float* cos, const float* sin, int split, const void* wqA, const void* wkA, const void* wqB, const void* wkB,
+                             float eps, float scale, void* workspace, void* stream) {
+  TD_CHECK_ARG(qkv && cos && sin && q_col >= 0 && k_col >= 0 && v_col >= 0 && (q_col | k_col | v_col) % 8 == 0, "td_attention_fp8_qk_rope: projection buffer, both tables, 16-byte aligned column offsets");
+  TdAttnParams p;
+  p.Q = (const bf16_t*)qkv + q_col; p.K = (const bf16_t*)qkv + k_col; p.V = (const bf16_t*)qkv + v_col; p.O = (bf16_t*)o;
+  p.batch = 1; p.Sq = S; p.Skv = S; p.Hq = H; p.Hkv = H; p.head_dim = 128;
+  p.ldq = (int)ld; p.ldkv = (int)ld; p.ldo = (int)ldo; p.scale = scale; p.f8_ws = workspace; p.variant = ((g_attn_variant & 1) ? 0x1000 : 0) | ((g_attn_variant & 2) ? 0x2000 : 0);
+  p.rope_cos = cos; p.rope_sin = sin; p.rope_split = split; p.rope_eps = eps;
+  p.rope_wqA = (const bf16_t*)wqA; p.rope_wkA = (const bf16_t*)wkA; p.rope_wqB = (const bf16_t*)wqB; p.rope_wkB = (const bf16_t*)wkB;
+  // q is rounded to bf16 as td_qk_norm_rope_bf16 leaves it and scaled in the pack pass, as td_attention_fp8 does (the FLUX engine folds the
+  // scale in front of that rounding instead: TdQkRopeParams::q_premul on both of its paths)
+  return td_attn_fp8_launch(p, (hipStream_t)stream);
+}
+
 int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
                              const int* seg_starts, int n_seg, int max_len, int Hq, int Hkv, float scale, void* stream) {
   TD_CHECK_ARG(seg_starts && n_seg > 0 && max_len > 0, "td_attention_varlen: empty segment list");

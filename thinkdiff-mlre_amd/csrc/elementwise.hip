@@ -3,6 +3,7 @@
 // Rounding points mirror the reference's bf16 torch pipeline (each torch op rounds to bf16).
 #include "td_common.h"
 #include "td_kernels.h"
+#include "qk_rope_math.h"
 
 namespace {
 
@@ -186,16 +187,12 @@ __global__ __launch_bounds__(256) void td_qk_norm_rope_kernel(const TdQkRopePara
     unpack8(*(const u32x4_t*)hp, x);
     const bf16_t* w = is_k ? wk : wq;
     if (w) {
-      float sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sq += x[i] * x[i];
+      float sq = qk_sumsq8(x);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
-      const float rstd = rsqrtf(sq * (1.0f / 128.0f) + p.eps);
       float wv[8];
       unpack8(*(const u32x4_t*)(w + l16 * 8), wv);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = rbf(rbf(x[i] * rstd) * wv[i]);
+      qk_norm8(x, qk_rstd(sq, p.eps), wv);
     }
     float y[8];
     if (p.rotate_half) {
@@ -208,11 +205,7 @@ __global__ __launch_bounds__(256) void td_qk_norm_rope_kernel(const TdQkRopePara
         y[i] = p.rotate_half == 2 ? rbf(x[i] * cs[i]) + rbf(rot * sn[i]) : x[i] * cs[i] + rot * sn[i];
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 8; i += 2) {
-        y[i] = x[i] * cs[i] - x[i + 1] * sn[i];
-        y[i + 1] = x[i + 1] * cs[i + 1] + x[i] * sn[i + 1];
-      }
+      qk_rope_pairs8(x, cs, sn, y);
     }
     if (!is_k && p.q_premul != 1.0f) {
 #pragma unroll

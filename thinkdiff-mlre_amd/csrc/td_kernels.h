@@ -84,6 +84,14 @@ struct TdAttnParams {
   uint8_t* q8 = nullptr; int ldq8 = 0; const float* q8_inv = nullptr; unsigned* q8_amax = nullptr;
   // td_attn_fp8_launch only: td_attn_fp8_ws_bytes(Sq, Skv, Hq) bytes of scratch for the packed e4m3 operands
   void* f8_ws = nullptr;
+  // td_attn_fp8_launch only (rope_cos != null): Q / K are the RAW projection outputs and the pack pass applies the per-head
+  // QK-RMSNorm + interleaved-pair rotary embedding of td_qk_norm_rope_kernel on its way (same arithmetic, same summation order and
+  // the same bf16 rounding points: bit-identical to the two-pass form), so that pass and its HBM round trip disappear.  Needs
+  // Sq == Skv (q and k rows are the same tokens); rows < rope_split take the A norm weights, the rest B (null: no norm).
+  const float* rope_cos = nullptr; const float* rope_sin = nullptr;   // [Sq,128] fp32
+  const bf16_t* rope_wqA = nullptr; const bf16_t* rope_wkA = nullptr; const bf16_t* rope_wqB = nullptr; const bf16_t* rope_wkB = nullptr;
+  int rope_split = 0; float rope_eps = 1e-6f;
+  float rope_q_premul = 1.0f;   // as TdQkRopeParams::q_premul (then q_prescaled = 1)
 };
 size_t td_attn_streamk_ws_bytes();
 int td_attn_device_cus(int dev);

@@ -119,6 +119,7 @@ def _declare(L):
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
         "td_attention_fp8": [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, f32, vp, vp],
+        "td_attention_fp8_qk_rope": [vp, i64, i32, i32, i32, vp, i64, i32, i32, vp, vp, i32, vp, vp, vp, vp, f32, f32, vp, vp],
         "td_sample_top_p_bf16": [vp, i64, i32, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, vp, vp],
     }
     for name, args in sig.items():
@@ -213,6 +214,24 @@ def attention_fp8(q, k, v, out, H, scale=None, workspace=None):
     assert ws.dtype == torch.uint8 and ws.numel() >= nbytes and ws.is_contiguous()
     check(L.td_attention_fp8(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), Sq, Skv, H,
                              float(scale), ptr(ws), stream_ptr()))
+    return out
+
+
+def attention_fp8_qk_rope(qkv, out, H, cos, sin, split=0, wqA=None, wkA=None, wqB=None, wkB=None, eps=1e-6, scale=None, workspace=None):
+    """td_attention_fp8 fed from the RAW fused projection qkv [S, 3*H*128] (q | k | v): QK-RMSNorm + RoPE happen inside the pack
+    pass (td_attention_fp8_qk_rope); qkv is not modified.  Returns out."""
+    assert qkv.dim() == 2 and qkv.dtype == torch.bfloat16 and qkv.stride(1) == 1 and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    S, D = qkv.shape[0], H * 128
+    assert qkv.shape[1] >= 3 * D and cos.dtype == torch.float32 and cos.shape == (S, 128) and sin.shape == (S, 128)
+    if scale is None:
+        scale = 128 ** -0.5
+    L = lib()
+    L.td_attention_fp8_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = int(L.td_attention_fp8_workspace_bytes(S, S, H))
+    ws = workspace if workspace is not None else torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+    assert ws.dtype == torch.uint8 and ws.numel() >= nbytes and ws.is_contiguous()
+    check(L.td_attention_fp8_qk_rope(ptr(qkv), qkv.stride(0), 0, D, 2 * D, ptr(out), out.stride(0), S, H, ptr(cos), ptr(sin), split,
+                                     ptr(wqA), ptr(wkA), ptr(wqB), ptr(wkB), float(eps), float(scale), ptr(ws), stream_ptr()))
     return out
 
 
