@@ -161,34 +161,35 @@ def fp8_leg(pipe, G, rank, steps=2):
         v = pol.get(key, {}).get("pixel_rmse_vs_oracle")
         return (f"{v:.2e} on [0,1] vs the 28-step ORACLE fixture tests/golden/full_depth_cfg5_T258.pt (tests/test_flux_full_depth_gpu.py; "
                 f"{par.get('_file', 'profiles/')}); HIP bf16 itself: {pol.get('bf16', {}).get('pixel_rmse_vs_oracle', float('nan')):.2e}") if v is not None else "not recorded"
-    return {"value": steps * G / el, "unit": "images/s/GPU", "steps": steps, "ms_per_step": el / steps * 1e3, "images_per_step": G,
-            "one_image_in_flight": 1.0 / single,
-            "dtype": "fp8_e4m3 block-GEMM operands (per-channel weight / per-token activation scales), fp32 accumulate, bf16 elsewhere",
-            "workload": "BASELINE config 5 shape per GPU: ThinkDiff-CLIP two-image composition, T_txt=258 (2 x 65 aligner + 128 T5), joint S=4354, "
-                        "1024x1024, 28 steps, FLUX.1-dev shape, denoise + VAE decode + uint8/PIL",
-            "whole_step_tflops_per_gpu": fl * G / (el / steps) / 1e12, "frac_of_fp8_dense_peak": fl * G / (el / steps) / 1e12 / FP8_DENSE_PEAK_TFLOPS,
-            "pixel_rmse_vs_oracle": rmse("fp8"), "inside_1e-2_bar": bool(pol.get("fp8", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2),
-            "int8_all_block_linears": {"value": steps * G / el_i, "one_image_in_flight": 1.0 / single_i,
-                                       "dtype": "int8 block-GEMM operands (symmetric, per-channel weight / per-token activation scales), exact int32 accumulate "
-                                                "(v_mfma_i32_16x16x64_i8, the fp8 MFMA rate), bf16 elsewhere",
-                                       "whole_step_tflops_per_gpu": fl * G / (el_i / steps) / 1e12,
-                                       "pixel_rmse_vs_oracle": rmse("int8"),
-                                       "inside_1e-2_bar": bool(pol.get("int8", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2),
-                                       "history_scales": {"value": steps * G / el_h, "one_image_in_flight": 1.0 / single_h,
-                                                          "what": "td_flux_set_act_scales(1): per-token scales of the MLP operands from the previous denoise step x 1.25, "
-                                                                  "int8 written by the producing GEMM epilogues (no quantisation pass over them)",
-                                                          "pixel_rmse_vs_oracle": rmse("int8_history"),
-                                                          "inside_1e-2_bar": bool(pol.get("int8_history", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)},
-                                       "history_scales_fp8_attention": {
-                                           "value": steps * G / el_a, "one_image_in_flight": 1.0 / single_a,
-                                           "what": "the line above + td_flux_set_attention(TD_ATTENTION_FP8): QK^T and P.V of every joint attention on "
-                                                   "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 q / k / v under power-of-two scales, csrc/attention_fp8.hip)",
-                                           "whole_step_tflops_per_gpu": fl * G / (el_a / steps) / 1e12,
-                                           "pixel_rmse_vs_oracle": rmse("int8_history_attn8"),
-                                           "inside_1e-2_bar": bool(pol.get("int8_history_attn8", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)}},
-            "single_stream_blocks_only": {"value": steps * G / el_s, "one_image_in_flight": 1.0 / single_s, "fp8_gemms": ["single_in", "single_out"],
-                                          "pixel_rmse_vs_oracle": rmse("fp8_single"),
-                                          "inside_1e-2_bar": bool(pol.get("fp8_single", {}).get("pixel_rmse_vs_oracle", 1.0) <= 1e-2)}}
+    def entry(key, elapsed, single_s, dtype, what, peak=FP8_DENSE_PEAK_TFLOPS):
+        v = pol.get(key, {}).get("pixel_rmse_vs_oracle")
+        return {"value": steps * G / elapsed, "unit": "images/s/GPU", "one_image_in_flight": 1.0 / single_s, "dtype": dtype, "what": what,
+                "whole_step_tflops_per_gpu": fl * G / (elapsed / steps) / 1e12, "frac_of_8bit_dense_peak": fl * G / (elapsed / steps) / 1e12 / peak,
+                "pixel_rmse_vs_oracle": rmse(key), "inside_1e-2_bar": bool(v is not None and v <= 1e-2)}
+
+    e4m3 = "fp8_e4m3 block-GEMM operands (per-channel weight / per-token activation scales), fp32 accumulate, bf16 elsewhere"
+    i8 = "int8 block-GEMM operands (symmetric, per-channel weight / per-token activation scales), exact int32 accumulate (v_mfma_i32_16x16x64_i8, the fp8 MFMA rate)"
+    policies = {
+        "e4m3_all_block_linears": entry("fp8", el, single, e4m3, "td_flux_set_precision(TD_PRECISION_FP8_E4M3), every block Linear"),
+        "e4m3_single_stream_blocks_only": entry("fp8_single", el_s, single_s, e4m3, "the 38 single-stream blocks in e4m3, the 19 double-stream blocks in bf16 (td_flux_set_fp8_gemms)"),
+        "int8_all_block_linears": entry("int8", el_i, single_i, i8 + ", bf16 elsewhere", "td_flux_set_precision(TD_PRECISION_INT8), every block Linear, activation scales measured on the spot"),
+        "int8_history_scales": entry("int8_history", el_h, single_h, i8 + ", bf16 elsewhere",
+                                     "the line above + td_flux_set_act_scales(1): per-token scales of the MLP operands from the previous denoise step x 1.25, int8 written by the "
+                                     "producing GEMM / attention epilogues (no quantisation pass over them)"),
+        "int8_history_scales_e4m3_attention": entry("int8_history_attn8", el_a, single_a, i8 + "; QK^T and P.V of the joint attention on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 q / k / v / "
+                                                    "probabilities under power-of-two scales, fp32 accumulate and softmax state); bf16 elsewhere",
+                                                    "the line above + td_flux_set_attention(TD_ATTENTION_FP8) (csrc/attention_fp8.hip; QK-RMSNorm + RoPE inside its pack pass)"),
+    }
+    inside = {k: v for k, v in policies.items() if v["inside_1e-2_bar"]}
+    best = max(inside or policies, key=lambda k: policies[k]["value"])
+    head = dict(policies[best])
+    head.update({"policy": best, "steps": steps, "ms_per_step": steps * G / head["value"] / steps * 1e3, "images_per_step": G,
+                 "workload": "BASELINE config 5 shape per GPU: ThinkDiff-CLIP two-image composition, T_txt=258 (2 x 65 aligner + 128 T5), joint S=4354, "
+                             "1024x1024, 28 steps, FLUX.1-dev shape, denoise + VAE decode + uint8/PIL",
+                 "selection": "`value` = the fastest 8-bit policy whose committed full-depth parity record is inside the 1e-2 pixel-RMSE bar against the 28-step "
+                              "oracle fixture (none inside: the fastest); every measured policy is listed under `policies`",
+                 "policies": policies})
+    return head
 
 
 def _parity_record():

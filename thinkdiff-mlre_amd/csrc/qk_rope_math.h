@@ -9,10 +9,10 @@
 __device__ __forceinline__ float qk_sumsq8(const float (&x)[8]) {
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sq += x[i] * x[i];
+  for (int i = 0; i < 8; ++i) sq = __builtin_fmaf(x[i], x[i], sq);
   return sq;
 }
-__device__ __forceinline__ float qk_rstd(float sumsq128, float eps) { return rsqrtf(sumsq128 * (1.0f / 128.0f) + eps); }
+__device__ __forceinline__ float qk_rstd(float sumsq128, float eps) { return rsqrtf(__builtin_fmaf(sumsq128, 1.0f / 128.0f, eps)); }
 // x <- bf16(bf16(x * rstd) * w): the two roundings of the bf16 RMSNorm module
 __device__ __forceinline__ void qk_norm8(float (&x)[8], float rstd, const float (&w)[8]) {
 #pragma unroll
@@ -20,9 +20,13 @@ __device__ __forceinline__ void qk_norm8(float (&x)[8], float rstd, const float 
 }
 // interleaved pairs (2i, 2i+1); cos / sin tables are repeat-interleaved, fp32
 __device__ __forceinline__ void qk_rope_pairs8(const float (&x)[8], const float (&cs)[8], const float (&sn)[8], float (&y)[8]) {
+  // Spelled out (the sin product rounded to fp32, the cos product fused into the sum): left to the compiler, which product of
+  // `a * b - c * d` it contracts depends on the surrounding code, and the two kernels that share this would differ in the last bit.
+#pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
-    y[i] = x[i] * cs[i] - x[i + 1] * sn[i];
-    y[i + 1] = x[i + 1] * cs[i + 1] + x[i] * sn[i + 1];
+    const float p0 = x[i + 1] * sn[i], p1 = x[i] * sn[i + 1];
+    y[i] = __builtin_fmaf(x[i], cs[i], -p0);
+    y[i + 1] = __builtin_fmaf(x[i + 1], cs[i + 1], p1);
   }
 }

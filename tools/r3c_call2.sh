@@ -4,6 +4,10 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout -k 10 500 python -m pytest tests/test_attention_fp8_gpu.py -x -q -m gpu > gpurun_out/r3c_attn8_tests2.log 2>&1 || { tail -40 gpurun_out/r3c_attn8_tests2.log; exit 1; }
 tail -2 gpurun_out/r3c_attn8_tests2.log
+timeout -k 10 500 python -m pytest tests/test_attention_gpu.py -x -q -m gpu -k "ring or prescaled" > gpurun_out/r3c_attn_ring_tests.log 2>&1 || { tail -40 gpurun_out/r3c_attn_ring_tests.log; exit 1; }
+tail -2 gpurun_out/r3c_attn_ring_tests.log
+timeout -k 10 300 python tools/bench_ops.py attn > gpurun_out/r3c_attn_ring_ab.log 2>&1 || { tail -20 gpurun_out/r3c_attn_ring_ab.log; exit 1; }
+cat gpurun_out/r3c_attn_ring_ab.log
 B8="--precision int8 --act-scales history --attention fp8 --no-cpu-baseline --no-fp8-leg"
 timeout -k 10 200 python bench.py $B8 > gpurun_out/r3c_i8a8_fused.json 2> gpurun_out/r3c_i8a8_fused.err || exit 2
 TD_ATTN8_NO_FUSE=1 timeout -k 10 200 python bench.py $B8 > gpurun_out/r3c_i8a8_twopass.json 2> gpurun_out/r3c_i8a8_twopass.err || exit 3
