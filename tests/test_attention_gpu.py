@@ -187,31 +187,6 @@ def _rel_close(a, b, tol=2.0 ** -7):
     return bool((a - b).abs().max() <= tol * b.abs().max())
 
 
-@pytest.mark.parametrize("S,H", [(4289, 24), (4354, 24), (1000, 80), (700, 130)])
-def test_ring_form_matches_two_slot_form(hip, S, H):
-    """The four-slot ring forms of the persistent kernel (variant bits 0x2000 / 0x4000: tiles staged three ahead, counted vmcnt; LDS-DMA
-    pieces issued between the P.V MFMAs, at the tile top, or between the score MFMAs) run the same tile math in the same order as the two-slot form: equal outputs, including items split
-    between two workgroups and parts of one to three tiles."""
-    g = torch.Generator(device="cuda").manual_seed(S + H)
-    qkv = torch.randn(1, S, 3 * H * 128, generator=g, device="cuda").bfloat16()
-    qkv[:, :, :H * 128] = (qkv[:, :, :H * 128].float() * ((128 ** -0.5) * 1.4426950408889634)).bfloat16()
-    q, k, v = qkv[:, :, :H * 128], qkv[:, :, H * 128:2 * H * 128], qkv[:, :, 2 * H * 128:]
-    lib = hip.lib()
-    cur = lib.td_attention_set_variant(0)
-    outs = []
-    try:
-        for var in (0x800, 0x2800, 0x4800, 0x6800):
-            lib.td_attention_set_variant(var)
-            out = torch.zeros(1, S, H * 128, dtype=torch.bfloat16, device="cuda")
-            hip.attention(q, k, v, out, H, H)
-            torch.cuda.synchronize()
-            outs.append(out)
-    finally:
-        lib.td_attention_set_variant(cur)
-    assert torch.isfinite(outs[1].float()).all()
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
-
-
 @pytest.mark.parametrize("S,H", [(449, 4), (4289, 24), (4354, 24)])
 def test_prescaled_q_form(hip, S, H):
     """The form the FLUX engine uses: q arrives multiplied by scale * log2(e) (rounded to bf16 once, where RoPE rounds it), the

@@ -237,25 +237,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
 // workspace (one per engine context / stream: concurrent launches must not share it) is zeroed when it is created.
 // ---------------------------------------------------------------------------------------------
 
-// RING (round 3): a ring of FOUR K | V slots instead of two.  A tile is staged three tiles ahead of its first reader, its LDS-DMA pieces
-// are issued one at a time between the P.V MFMAs of the running tile (a piece costs ~60 issue cycles: invisible under a 32-cycle MFMA
-// pair of the two waves of a SIMD, and a quarter of the tile when all eight waves issue theirs together right behind the barrier, as the
-// two-slot form must), the top of a tile waits on a COUNTED vmcnt (the younger stage stays in flight across the barrier), and the first
-// two K fragments of the next tile are read under the last P.V MFMAs, so the score MFMAs start right behind the barrier.  The protocol
-// of csrc/attention_fp8.hip's kernel, where it was measured first.
-template <int NWAVES, bool XCD_REMAP, bool PRE = false, bool RS = true, int RING = 0>
+template <int NWAVES, bool XCD_REMAP, bool PRE = false, bool RS = true>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kernel(const TdAttnParams p, char* __restrict__ ws,
                                                                                   const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NSLOT = RING ? 4 : 2;      // RING 1: pieces under the P.V MFMAs; 2: all at the tile top (as the two-slot form); 3: under the score MFMAs
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 .. NSLOT-1 | V slot 0 .. NSLOT-1 | ticket word]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K slot 0 | K slot 1 | V slot 0 | V slot 1 | ticket word]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h5 = lane >> 5;
   const int l31 = lane & 31;
   unsigned* const cnt = (unsigned*)ws + 16;
-  TD_LDS unsigned* const ticket_lds = (TD_LDS unsigned*)(smem + 2 * NSLOT * TILE_BYTES);
+  TD_LDS unsigned* const ticket_lds = (TD_LDS unsigned*)(smem + 4 * TILE_BYTES);
 
   // logical range of this workgroup: with XCD_REMAP, workgroups that share an XCD (equal blockIdx % 8 under round-robin
   // placement; speed only) take neighbouring ranges = neighbouring query tiles of the same heads = the same K/V in that L2
@@ -294,7 +287,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       const unsigned swz = (vq << 2) | ((2 * jj + h5) & 3);
 #pragma unroll
       for (int db = 0; db < 4; ++db)
-        va[jj][db] = lds0 + NSLOT * TILE_BYTES + (4 * h5 + vq + 8 * jj) * 256 + (((4 * db + vchunk) ^ swz) << 4) + 8 * (vp & 1);
+        va[jj][db] = lds0 + 2 * TILE_BYTES + (4 * h5 + vq + 8 * jj) * 256 + (((4 * db + vchunk) ^ swz) << 4) + 8 * (vp & 1);
     }
   }
 
@@ -329,33 +322,21 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       const int chunk = (lane & 15) ^ swz;
       voffK[s] = (unsigned)(g * 4 + srow) * (unsigned)p.ldkv * 2u + (unsigned)(kvhead * D + chunk * 8) * 2u;
     }
-    // one LDS-DMA piece (1 KiB: 4 key rows) of tile t: piece pc = 2 s + (0: K, 1: V) of this wave's 2 SG pieces
-    auto stage_piece = [&](int slot, int t, int pc) {
+    auto stage = [&](int slot, int t) {
       const unsigned tile_off = (unsigned)t * KV_TILE * (unsigned)p.ldkv * 2u;
-      const int sg = pc >> 1;
-      const int g = wid + NWAVES * sg;
-      if (GROUPS % NWAVES == 0 || g < GROUPS) {
-        if (pc & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(smem + (NSLOT + slot) * TILE_BYTES + g * 1024), 16, voffK[sg] + tile_off, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(smem + slot * TILE_BYTES + g * 1024), 16, voffK[sg] + tile_off, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < SG; ++s) {
+        const int g = wid + NWAVES * s;
+        if (GROUPS % NWAVES == 0 || g < GROUPS) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(smem + slot * TILE_BYTES + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(smem + (2 + slot) * TILE_BYTES + g * 1024), 16, voffK[s] + tile_off, 0, 0, 0);
+        }
       }
     };
-    auto stage = [&](int slot, int t) {
-#pragma unroll
-      for (int pc = 0; pc < 2 * SG; ++pc) stage_piece(slot, t, pc);
-    };
-    constexpr int VMOPS = 2 * SG;      // vector-memory operations of one stage() per wave (RING: GROUPS % NWAVES == 0)
-    static_assert(!RING || (GROUPS % NWAVES == 0 && 2 * SG == 4), "the ring form spreads exactly four pieces per wave over the P.V MFMAs");
-    if constexpr (RING) {
-      // every iteration stages exactly one tile (indices past the part re-load its last tile into a slot nobody reads), so the number
-      // of operations in flight is the same at every barrier and the staging code has no branch
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the previous part's surplus stages and output stores are done ...
-      __builtin_amdgcn_s_barrier();                                     // ... and so are everyone's reads of the ring
-    } else {
-      __syncthreads();          // the previous part's last tile is no longer read by any wave
-      stage(0, kb);
-    }
+    __syncthreads();          // the previous part's last tile is no longer read by any wave
+    stage(0, kb);
 
-    bf16x8_t qf[8];      // (ring: loaded AHEAD of the three opening stages, so that the wait for q does not cover them)
+    bf16x8_t qf[8];
     {
       const unsigned qoff = (unsigned)(q0 + l31) * (unsigned)p.ldq * 2u + (unsigned)(head * D + 8 * h5) * 2u;
 #pragma unroll
@@ -364,7 +345,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
         qf[ks] = __builtin_bit_cast(bf16x8_t, v);
       }
     }
-    if constexpr (RING) stage(0, kb);
 
     f32x16_t o[4];
 #pragma unroll
@@ -376,40 +356,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     for (int rr = 0; rr < 16; ++rr) lacc[rr] = 0.f;
     float m_run = 0.f;
     bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};
-    bf16x8_t kpre[2];      // RING: the first two K fragments of the coming tile
-    if constexpr (RING) {
-      stage(1, min(kb + 1, ke - 1));
-      stage(2, min(kb + 2, ke - 1));
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VMOPS) : "memory");      // tile kb (and q) landed: everything but the two younger stages
-      __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int e = 0; e < 2; ++e) kpre[e] = *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e]);
-    }
-
     auto tile = [&](const int t, auto slot_tag) {
       constexpr unsigned SLOT = decltype(slot_tag)::value;
       constexpr unsigned PO = SLOT * TILE_BYTES;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t landed (explicit: see the plain-grid kernel) ...
+      __syncthreads();                                        // ... and everyone's; the other slot is no longer read
+      if (t + 1 < ke) stage(SLOT ^ 1, t + 1);
+
       f32x16_t st[2];
-      if constexpr (RING) {
-        // my pieces of tile t+1 landed (tile t+2 may still be in flight); behind the barrier everyone's are visible and the slot of
-        // tile t-1 has no reader left
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMOPS) : "memory");
-        __builtin_amdgcn_s_barrier();
-        constexpr int FREE = (SLOT + 3) % NSLOT;
-        const int t3 = min(t + 3, ke - 1);
-        if constexpr (RING == 2) stage(FREE, t3);
-        if constexpr (RING == 3) {
-          auto shook = [&](int e) { stage_piece(FREE, t3, e >> 2); };
-          attn_tile_scores<PO, true>(st, qf, kone, qnegm, ka, kpre, shook);
-        } else {
-          attn_tile_scores<PO, true>(st, qf, kone, qnegm, ka, kpre);
-        }
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t landed (explicit: see the plain-grid kernel) ...
-        __syncthreads();                                        // ... and everyone's; the other slot is no longer read
-        if (t + 1 < ke) stage(SLOT ^ 1, t + 1);
-        attn_tile_scores<PO>(st, qf, kone, qnegm, ka);
-      }
+      attn_tile_scores<PO>(st, qf, kone, qnegm, ka);
 
       const int key0 = t * KV_TILE;
       if (key0 + KV_TILE > Skv) {        // last tile: keys >= Skv are masked
@@ -422,27 +377,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
           }
       }
 
-      if constexpr (RING) {
-        constexpr unsigned NEXT = ((SLOT + 1) % NSLOT) * TILE_BYTES;
-        constexpr int FREE = (SLOT + 3) % NSLOT;
-        const int t3 = min(t + 3, ke - 1);
-        auto hook = [&](int e) {
-          if (RING == 1 && (e & 3) == 3) stage_piece(FREE, t3, e >> 2);
-          if (e >= 14) kpre[e - 14] = *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e - 14] + NEXT);
-        };
-        attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5, hook);
-      } else {
-        attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5);
-      }
+      attn_tile_softmax_pv<PO, PRE, RS>(st, o, lacc, m_run, qnegm, t == kb, c, va, h5);
     };
-    if constexpr (RING) {
-      for (int t = kb;;) {
-        tile(t, std::integral_constant<unsigned, 0>{}); if (++t >= ke) break;
-        tile(t, std::integral_constant<unsigned, 1>{}); if (++t >= ke) break;
-        tile(t, std::integral_constant<unsigned, 2>{}); if (++t >= ke) break;
-        tile(t, std::integral_constant<unsigned, 3>{}); if (++t >= ke) break;
-      }
-    } else {
+    {
       int t = kb;
       for (; t + 1 < ke; t += 2) {
         tile(t, std::integral_constant<unsigned, 0>{});
@@ -629,20 +566,7 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
       if (int rc = sk_pooled_workspace(dev, cus, stream, &ws)) return rc;
     }
     constexpr int lds_sk = lds + 16;        // + the ticket word
-    if (p.q_prescaled && (p.variant & 0x6000)) {      // A/B: the four-slot ring forms (variant bits 0x2000 / 0x4000: mode 1, 2, 3)
-      constexpr int lds_ring = 8 * TILE_BYTES + 16;
-      static std::atomic<unsigned long long> a9[3] = {};
-      const int mode = (p.variant >> 13) & 3;
-      auto go = [&](auto kernel, std::atomic<unsigned long long>& once) -> int {
-        if (int e = set_lds_attr_once(kernel, lds_ring, once, dev)) return e;
-        hipLaunchKernelGGL(kernel, dim3(cus), dim3(NW * 64), lds_ring, stream, q, ws, (int)grid.x, nt);
-        return 0;
-      };
-      int rc = mode == 1 ? go(td_attn_fwd_d128_streamk_kernel<NW, true, true, true, 1>, a9[0])
-             : mode == 2 ? go(td_attn_fwd_d128_streamk_kernel<NW, true, true, true, 2>, a9[1])
-                         : go(td_attn_fwd_d128_streamk_kernel<NW, true, true, true, 3>, a9[2]);
-      if (rc) return rc;
-    } else if (p.q_prescaled) {
+    if (p.q_prescaled) {
       static std::atomic<unsigned long long> a7{0};
       if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true, true>, lds_sk, a7, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);

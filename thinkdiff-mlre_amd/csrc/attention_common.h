@@ -76,15 +76,9 @@ __device__ __forceinline__ bf16x4_t attn_ds_read_tr16(const unsigned addr) {
 //    into a 16-register accumulator, every register the complete sum over the 64 keys) replaces 32 adds per tile and lane and
 //    the half swap at the end; the sum is over the bf16-rounded probabilities the P.V product consumes.
 // Per 64-key tile and wave: 38 MFMAs (was 32) against ~32 v_exp + 16 v_cvt_pk + 16 v_max3 (+ rare rescales).
-// PREK: the first KPF K fragments were read by the caller already (the ring kernel reads them at the end of the previous tile, under
-// its P.V MFMAs, so that the score MFMAs start right behind the barrier).
-struct AttnNoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-// SHOOK: shook(e) is called behind score MFMA e = 3, 7, 11, 15 and issues one vector-memory instruction (ring form 3).
-template <unsigned PO, bool PREK = false, typename SHOOK = AttnNoHook>
+template <unsigned PO>
 __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8_t (&qf)[8], const bf16x8_t kone, const bf16x8_t qnegm,
-                                                 const unsigned (&ka)[8], const bf16x8_t* kpre = nullptr, const SHOOK shook = SHOOK()) {
+                                                 const unsigned (&ka)[8]) {
   // K fragments are fetched KPF MFMAs ahead of their use (pinned: hipcc would issue each read right before its consumer and
   // expose the LDS latency 16 times per tile); depth re-measured in-process at S = 4289: 2 beats 4 and 6 by 2 % (1 ties)
   constexpr int KPF = 2;
@@ -93,14 +87,9 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
     return *(const TD_LDS bf16x8_t*)(uintptr_t)(ka[e & 7] + PO + (e >> 3) * 32 * 256);
   };
   bf16x8_t kf[16];
-  if constexpr (PREK) {
 #pragma unroll
-    for (int e = 0; e < KPF; ++e) kf[e] = kpre[e];
-  } else {
-#pragma unroll
-    for (int e = 0; e < KPF; ++e) kf[e] = kread(e);
-    __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
-  }
+  for (int e = 0; e < KPF; ++e) kf[e] = kread(e);
+  __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     if ((e & 7) == 0) {      // the reference point first: st = 1 . (-m)
@@ -111,12 +100,6 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
     st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], st[e >> 3], 0, 0, 0);
     if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if constexpr (!std::is_same<SHOOK, AttnNoHook>::value) {
-      if ((e & 3) == 3) {
-        shook(e);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-    }
   }
 }
 
@@ -124,12 +107,9 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
 // zero and m_run is 0: the reference point is set to the tile's row maximum whatever it is.
 // RS: row sums on the matrix pipe (lacc); otherwise they are added on the VALU into lacc[0] as HALF sums (the caller adds the
 // two lane halves at the end) -- the A/B of which pipe has room on a given shape.
-// HOOK: the ring kernel's work that rides in the shadow of the P.V MFMAs -- hook(e) is called behind P.V MFMA e (0..15) and issues
-// at most ONE vector-memory instruction (an LDS-DMA piece of a later tile) for e % 4 == 3 and at most one LDS read for e >= 14 (the next
-// tile's first K fragments); the instruction order is pinned accordingly.
-template <unsigned PO, bool PRE, bool RS = true, typename HOOK = AttnNoHook>
+template <unsigned PO, bool PRE, bool RS = true>
 __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t (&o)[4], f32x16_t& lacc, float& m_run, bf16x8_t& qnegm,
-                                                     const bool first, const float c, const unsigned (&va)[2][4], const int h5, const HOOK hook = HOOK()) {
+                                                     const bool first, const float c, const unsigned (&va)[2][4], const int h5) {
   const float cc = PRE ? 1.0f : c;
   float mx = st[0][0];
 #pragma unroll
@@ -183,7 +163,7 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
   // The transposed V^T reads are INLINE ASM, with their own counted waits: behind an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)`
   // in front of the first __builtin_amdgcn_ds_read_tr16_b64 (its memory operand may alias the DMA's destination as far as the
   // compiler can tell; plain loads through an integer-cast address carry no such operand and are left alone), i.e. every wave waited
-  // for the NEXT tile's K | V in the middle of the running tile, whatever the ring depth.  LDS operations of a wave complete in order,
+  // for the NEXT tile's K | V in the middle of the running tile -- and the two-slot kernels had come to RELY on that wait (see their tile top).  LDS operations of a wave complete in order,
   // so `lgkmcnt(n)` with n = the reads issued behind the wanted pair is exact, and a compiler-inserted wait that does not know of
   // these reads can only wait longer than it means to.  The wait carries the fragment as an in/out operand so that its MFMA cannot
   // be scheduled above it; sched_barrier pins the read / wait / MFMA order (VALU and SALU work may still move across).
@@ -207,7 +187,6 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
     vf[0] = v0[e][0]; vf[1] = v0[e][1]; vf[2] = v0[e][2]; vf[3] = v0[e][3];
     vf[4] = v1[e][0]; vf[5] = v1[e][1]; vf[6] = v1[e][2]; vf[7] = v1[e][3];
     o[e & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[e >> 3][(e >> 2) & 1], o[e & 3], 0, 0, 0);
-    if constexpr (!std::is_same<HOOK, AttnNoHook>::value) hook(e);
     if constexpr (RS && (e & 3) == 3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[e >> 3][(e >> 2) & 1], lacc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0x006);
   });

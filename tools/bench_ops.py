@@ -256,7 +256,7 @@ def bench_gemmcold():
 def bench_attn():
     """Joint attention, in-process interleaved A/B of the kernel structures (variant 0 shipped / 1 one workgroup per item /
     2 persistent without the XCD range order), cold inputs (pool cycling)."""
-    names = {0: "shipped", 1: "wg-per-item", 0x800: "shipped-prescaled", 0x801: "wg-per-item-prescaled", 0x2800: "ring1-pv", 0x4800: "ring2-top", 0x6800: "ring3-qk"}
+    names = {0: "shipped", 1: "wg-per-item", 0x800: "shipped-prescaled", 0x801: "wg-per-item-prescaled"}
     for S, H in [(4289, 24), (4354, 24)]:
         W = H * 128
         pool = [torch.randn(1, S, 3 * W, device="cuda").bfloat16() for _ in range(6)]
