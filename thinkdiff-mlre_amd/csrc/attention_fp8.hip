@@ -235,10 +235,7 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
 // which the row sum -- taken over the same bytes -- cancels; 1.9 % rms remains, less than e4m3's own rounding of a probability).
 // It replaces 32 v_exp_f32 (8 issue cycles each) + 16 v_cvt_pk_fp8_f32 per tile and wave by 32 4-cycle conversions: the exp form
 // of this kernel is VALU-bound (rocprofv3: MFMA 35 %, VALU 61 % of the cycles, not overlapping), this one is not.
-// SKEW (A/B): waves 4-7 -- the second wave of every SIMD -- pass the tile's barrier BEHIND their score MFMAs instead of in front of them
-// (legal: the barrier of tile t-1 already made tile t visible, slots are still freed one tile late), so that the two waves of a SIMD
-// run half a tile apart: one's row maxima / conversions under the other's MFMAs.
-template <int NWAVES, bool XCD_REMAP, bool LIN, bool SKEW = false>
+template <int NWAVES, bool XCD_REMAP, bool LIN>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(const TdAttnParams p, const char* __restrict__ pk, const F8Layout lay,
                                                                                char* __restrict__ ws, const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -359,11 +356,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       using FREE = std::integral_constant<int, (SLOT + 3) % NSLOT>;
       // my pieces of tile t+1 landed (tile t+2 may still be in flight); after the barrier everyone's are visible and slot FREE
       // (tile t-1) has no reader left
-      const bool late = SKEW && wid >= NWAVES / 2;      // wave-uniform
-      if (!late) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMOPS) : "memory");
-        __builtin_amdgcn_s_barrier();
-      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMOPS) : "memory");
+      __builtin_amdgcn_s_barrier();
       const int ksc = (int)ksc_r[SLOT], vsc = (int)vsc_r[SLOT];
 
       // ---- S^T - ref = K8 . Q8^T - ref ------------------------------------------------------------------------------------
@@ -387,12 +381,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       for (int e = 0; e < 4; ++e) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-      if constexpr (SKEW) {
-        if (late) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMOPS) : "memory");
-          __builtin_amdgcn_s_barrier();
-        }
       }
 
       const int key0 = t * KV_TILE;
@@ -588,15 +576,14 @@ int td_attn_fp8_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_LAUNCH();
   const int G = min(cus * (8 / NW), n_items);       // a range is never shorter than an item: every item is split over at most two workgroups
   constexpr int lds = 8 * TILE8 + 16;
-  static std::atomic<unsigned long long> done[5] = {};
+  static std::atomic<unsigned long long> done[4] = {};
   auto go = [&](auto kernel, std::atomic<unsigned long long>& once, int threads) -> int {
     if (int e = td_attn_set_lds_attr((const void*)kernel, lds, once, dev)) return e;
     hipLaunchKernelGGL(kernel, dim3(G), dim3(threads), lds, stream, p, (const char*)p.f8_ws, lay, ws, n_qblk, nt);
     return 0;
   };
   int rc;
-  if (NW == 8 && lin && (p.variant & 0x4000)) rc = go(td_attn_fwd_d128_fp8_kernel<8, true, true, true>, done[4], 512);      // A/B: skewed wave halves
-  else if (NW == 8) rc = lin ? go(td_attn_fwd_d128_fp8_kernel<8, true, true>, done[0], 512) : go(td_attn_fwd_d128_fp8_kernel<8, true, false>, done[1], 512);
+  if (NW == 8) rc = lin ? go(td_attn_fwd_d128_fp8_kernel<8, true, true>, done[0], 512) : go(td_attn_fwd_d128_fp8_kernel<8, true, false>, done[1], 512);
   else rc = lin ? go(td_attn_fwd_d128_fp8_kernel<4, true, true>, done[2], 256) : go(td_attn_fwd_d128_fp8_kernel<4, true, false>, done[3], 256);
   if (rc) return rc;
   TD_CHECK_LAUNCH();
