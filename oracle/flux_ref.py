@@ -238,14 +238,15 @@ def _attention_fp8(q, k, v):
     B, H, S, hd = q.shape
     c = (hd ** -0.5) * math.log2(math.e)
     out = torch.empty(B, S, H * hd, dtype=q.dtype, device=q.device)
-    pad = (-S) % 64
+    Skv = k.shape[2]                     # (the joint attention has Skv == S; the kernel's entry point takes any pair)
+    pad = (-Skv) % 64
     for b in range(B):
         for h in range(H):
             q8, sq = _e8m0_quant(q[b, h].float() * c, (1,))
             k8, sk = _e8m0_quant(k[b, h].float(), (1,))
             vg = F.pad(v[b, h].float(), (0, 0, 0, pad)).view(-1, 64, hd)
             v8, sv = _e8m0_quant(vg, (1, 2))
-            vq = (v8 * sv).view(-1, hd)[:S]
+            vq = (v8 * sv).view(-1, hd)[:Skv]
             s = (q8 * sq) @ (k8 * sk).T
             ref = torch.ceil(s.amax(dim=1, keepdim=True))
             if FP8_ATTENTION_PROB == "linear":

@@ -135,6 +135,32 @@ def test_fp8_attention_vs_restatement_and_exact(hip, S, H):
     assert e_rest < 5e-3 and e_exact < 8e-2
 
 
+@pytest.mark.parametrize("Sq,Skv,H", [(300, 500, 2), (500, 300, 3), (1, 64, 1), (257, 65, 2)])
+def test_fp8_attention_different_query_and_key_counts(hip, Sq, Skv, H):
+    """td_attention_fp8 takes any (Sq, Skv) pair: more query tiles than key tiles (the pack pass then has query-only tiles), fewer,
+    a single query row, a ragged key tail of one row."""
+    g = torch.Generator().manual_seed(Sq * 1000 + Skv)
+    D = H * 128
+    q = torch.randn(Sq, D, generator=g).bfloat16()
+    kv = torch.randn(Skv, 2 * D, generator=g).bfloat16()
+    out = torch.zeros(Sq, D, dtype=torch.bfloat16, device="cuda")
+    kvd = kv.cuda()
+    hip.attention_fp8(q.cuda(), kvd[:, :D], kvd[:, D:], out, H)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    heads = lambda t, n: t.view(n, H, 128).transpose(0, 1)[None]  # noqa: E731
+    prev, R.FP8_ATTENTION = (R.FP8_ATTENTION, R.FP8_ATTENTION_PROB), True
+    R.FP8_ATTENTION_PROB = _PROB["form"]
+    try:
+        ref = R._attention(heads(q, Sq), heads(kv[:, :D].contiguous(), Skv), heads(kv[:, D:].contiguous(), Skv))[0]
+    finally:
+        R.FP8_ATTENTION, R.FP8_ATTENTION_PROB = prev
+    x = torch.softmax(heads(q, Sq)[0].float() @ heads(kv[:, :D].contiguous(), Skv)[0].float().transpose(-1, -2) / math.sqrt(128), dim=-1) @ heads(kv[:, D:].contiguous(), Skv)[0].float()
+    e_rest, e_exact = _rel(out, ref), _rel(out, x.transpose(0, 1).reshape(Sq, D))
+    print(f"Sq={Sq} Skv={Skv} H={H}: vs restatement {e_rest:.3e}, vs exact {e_exact:.3e}")
+    assert e_rest < 5e-3 and e_exact < 8e-2
+
+
 def test_fp8_attention_sharp_rows_and_large_magnitudes(hip):
     """Rows whose softmax is nearly one-hot (|q.k| large: the reference point moves often) and v far from unit scale."""
     S, H = 520, 2

@@ -12,3 +12,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 python tools/pmc_summary.py gpurun_out/r3d_pmc_sq td_ > gpurun_out/r3d_pmc_sq.txt
 rm -rf gpurun_out/r3d_pmc_fetch gpurun_out/r3d_pmc_write gpurun_out/r3d_pmc_sq
 echo done
+TD_BENCH_FORCE_DIST=1 timeout -k 10 200 python bench.py --workload config5 --prompts 8 --precision int8 --act-scales history --attention fp8 > gpurun_out/r3d_config5_int8_attn8_8prompts.json 2> gpurun_out/r3d_config5.err || exit 7
+cat gpurun_out/r3d_config5_int8_attn8_8prompts.json | cut -c1-300
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r3d_bench_line.json"))
+print("bf16", round(d["value"], 4), "one", round(d["one_image_in_flight"]["value"], 4), "gemm frac", round(d["roofline"]["frac"], 4), "attn frac", round(d["attention_roofline"]["frac"], 4))
+f = d["fp8"]
+print("8-bit value", round(f["value"], 4), f["policy"], {k: (round(v["value"], 3), v["inside_1e-2_bar"]) for k, v in f["policies"].items()})
+print("cpu", d["cpu_baseline"]["value"])
+PY
