@@ -228,6 +228,9 @@ int td_flux_set_condition(td_flux* f, const void* prompt_embeds, int T, const vo
 /* per schedule: t_eff (host, n floats) / g_eff = the values fed to the sinusoids (timestep*1000,
  * guidance*1000 after the pipeline's dtype casts); precomputes temb and every adaLN modulation */
 int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, void* stream);
+/* The extents a prepared context expects: image / text tokens of the last td_flux_set_condition (0 before it), latent channels, prepared
+ * timesteps.  Any out pointer may be NULL.  (The torch.ops layer checks tensor extents against it before handing pointers over.) */
+int td_flux_prepared_shape(const td_flux* f, int* img_tokens, int* txt_tokens, int* in_channels, int* n_steps);
 /* velocity[S_img,in_channels] = transformer(latents[S_img,in_channels]; prepared step) */
 int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, void* stream);
 /* Per-launch HIP-event trace of the engine's kernels (events recorded on the launch stream).
@@ -317,6 +320,9 @@ int td_vae_init_random(td_vae* f, uint64_t seed, float std, void* stream);
  * uint8 and/or image_chw bf16 [3,8h,8w] (= vae.decode output); either may be NULL. */
 int td_vae_decode(td_vae* f, const void* packed_latents, int h, int w, float scaling_factor, float shift_factor,
                   void* image_u8, void* image_chw, void* stream);
+/* The image size td_vae_decode writes for an h x w latent (2x per block but the last: 8h x 8w for the FLUX.1 VAE) and the channel count of
+ * a packed latent row (4 x latent_channels); out pointers may be NULL.  (The torch.ops layer sizes and checks its tensors with it.) */
+int td_vae_output_shape(const td_vae* f, int h, int w, int* H, int* W, int* packed_channels);
 /* GroupNorm (+ optional SiLU) over an NHWC image x[P,C]; workspace: td_groupnorm_workspace_floats() floats. */
 int td_groupnorm_nhwc_bf16(const void* x, void* y, int P, int C, int groups, float eps, const void* gamma,
                            const void* beta, int silu, float* workspace, void* stream);

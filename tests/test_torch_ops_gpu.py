@@ -68,3 +68,92 @@ def test_mixed_device_and_short_arguments_are_rejected(hip):
         O.attention(q, q.repeat(2, 1, 1), q.repeat(2, 1, 1), 2, 2, 0.088, False)   # k/v batch differs from q's
     with pytest.raises(RuntimeError):
         O.norm_rows(x.repeat(1, 2).contiguous(), False, 1e-6, None, 0, v.cpu(), v, None, None)
+
+
+def test_engine_ops_are_the_engine_and_check_extents(hip):
+    """flux_forward_ / flux_denoise_ / flux_denoise_multi_ / vae_decode_u8 / attention_fp8: the product models run the denoise loop through
+    these ops; each is the C-ABI call (bit-identical to the direct ctypes binding) and refuses tensors that do not match what the prepared
+    context expects (wrong row count, host tensor, wrong dtype, null handle)."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import flux_ref as R
+    import thinkdiff.ops  # noqa: F401
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+    O = torch.ops.thinkdiff_hip
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=1, num_single_layers=1, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+    m.load_state_dict(R.init_weights(cfg, seed=4))
+    g = torch.Generator().manual_seed(1)
+    h2 = w2 = 8
+    T, n = 20, 3
+    lat = torch.randn(h2 * w2, 64, generator=g).bfloat16().cuda()
+    m.set_condition(torch.randn(T, cfg.joint_attention_dim, generator=g).bfloat16().cuda(), torch.randn(cfg.pooled_projection_dim, generator=g).bfloat16().cuda(),
+                    R.latent_image_ids(h2, w2))
+    sig = [float(s) for s in R.make_sigmas(n, h2 * w2)]
+    m.set_timesteps([effective_scalar(s * 1000.0, torch.bfloat16) for s in sig[:-1]], 3500.0)
+    L, h = hip.lib(), int(m._h.value)
+    shp = [ctypes.c_int() for _ in range(4)]
+    hip.check(L.td_flux_prepared_shape(m._h, *[ctypes.byref(s) for s in shp]))
+    assert [s.value for s in shp] == [h2 * w2, T, 64, n]
+    # forward: op == ctypes
+    v_op = O.flux_forward_(h, lat, 1, torch.empty_like(lat))
+    v_c = torch.empty_like(lat)
+    hip.check(L.td_flux_forward(m._h, hip.ptr(lat), 1, hip.ptr(v_c), hip.stream_ptr()))
+    assert torch.equal(v_op, v_c) and torch.isfinite(v_op.float()).all() and float(v_op.float().abs().max()) > 0
+    # denoise: op == ctypes == the model method; multi == single
+    a, b, c = lat.clone(), lat.clone(), lat.clone()
+    assert O.flux_denoise_(h, a, sig) is a
+    arr = (ctypes.c_float * (n + 1))(*sig)
+    hip.check(L.td_flux_denoise(m._h, hip.ptr(b), ctypes.cast(arr, ctypes.c_void_p), n, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    O.flux_denoise_multi_([h], [c], sig, [int(torch.cuda.current_stream().cuda_stream)])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, m.denoise(lat.clone(), sig))
+    # rejected arguments
+    for bad in (lat[:-1].contiguous(), lat.cpu(), lat.float(), lat.t().contiguous().t()):
+        with pytest.raises(RuntimeError):
+            O.flux_forward_(h, bad, 0, torch.empty_like(lat))
+    with pytest.raises(RuntimeError):
+        O.flux_forward_(h, lat, n, torch.empty_like(lat))                       # step outside the prepared timesteps
+    with pytest.raises(RuntimeError):
+        O.flux_forward_(0, lat, 0, torch.empty_like(lat))
+    with pytest.raises(RuntimeError):
+        O.flux_denoise_(h, lat.clone(), [1.0])
+    with pytest.raises(RuntimeError):
+        O.flux_denoise_multi_([h, h], [lat.clone()], sig, [0])
+    # the 8-bit attention op == the ctypes binding
+    qkv = torch.randn(300, 3 * 256, generator=g).bfloat16().cuda()
+    o8 = O.attention_fp8(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], 2, 128 ** -0.5)
+    ref8 = hip.attention_fp8(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], torch.empty(300, 256, dtype=torch.bfloat16, device="cuda"), 2)
+    assert torch.equal(o8, ref8)
+    with pytest.raises(RuntimeError):
+        O.attention_fp8(qkv[:, :256], qkv[:, 256:512].cpu(), qkv[:, 512:].cpu(), 2, 0.088)
+
+
+def test_vae_decode_op(hip):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import vae_ref as V
+    import thinkdiff.ops  # noqa: F401
+    from thinkdiff.models.flux_vae import AutoencoderKLConfig, AutoencoderKLDecoder
+    O = torch.ops.thinkdiff_hip
+    cfg = V.tiny_config()
+    vae = AutoencoderKLDecoder(AutoencoderKLConfig(block_out_channels=cfg.block_out_channels), max_latent_size=(16, 16))
+    vae.load_state_dict(V.init_weights(cfg, seed=5))
+    h, w = 16, 8
+    packed = (torch.randn((h // 2) * (w // 2), 64, generator=torch.Generator().manual_seed(0)) * 0.8).bfloat16().cuda()
+    img = O.vae_decode_u8(int(vae._h.value), packed, h, w, float(vae.config.scaling_factor), float(vae.config.shift_factor))
+    assert img.dtype == torch.uint8 and img.shape == (vae.upscale * h, vae.upscale * w, 3)
+    u8 = torch.empty_like(img)
+    hip.check(hip.lib().td_vae_decode(vae._h, hip.ptr(packed), h, w, vae.config.scaling_factor, vae.config.shift_factor, u8.data_ptr(), None, hip.stream_ptr()))
+    assert torch.equal(img, u8) and torch.equal(img, vae.decode_packed(packed, h, w, output_type="np")) and int(img.max()) > int(img.min())
+    for bad in (packed[:-1].contiguous(), packed[:, :32].contiguous(), packed.cpu(), packed.float()):
+        with pytest.raises(RuntimeError):
+            O.vae_decode_u8(int(vae._h.value), bad, h, w, 1.0, 0.0)
+    with pytest.raises(RuntimeError):
+        O.vae_decode_u8(0, packed, h, w, 1.0, 0.0)

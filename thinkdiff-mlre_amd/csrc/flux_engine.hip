@@ -657,6 +657,16 @@ int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, vo
 }
 
 // One transformer evaluation: velocity[S_img, in_channels] = FluxTransformer2DModel(latents; step).
+// What the prepared context expects of its callers' buffers (the torch.ops layer validates tensor extents against it).
+int td_flux_prepared_shape(const td_flux* f, int* img_tokens, int* txt_tokens, int* in_channels, int* n_steps) {
+  TD_CHECK_ARG(f, "td_flux_prepared_shape: null context");
+  if (img_tokens) *img_tokens = f->cond_set ? f->S_img : 0;
+  if (txt_tokens) *txt_tokens = f->cond_set ? f->T : 0;
+  if (in_channels) *in_channels = f->cfg.in_channels;
+  if (n_steps) *n_steps = f->n_steps;
+  return TD_OK;
+}
+
 int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, void* stream) {
   TD_CHECK_ARG(f && latents && velocity, "td_flux_forward: null argument");
   TD_CHECK_ARG(f->cond_set && step >= 0 && step < f->n_steps, "td_flux_forward: step %d outside the %d prepared timesteps", step, f ? f->n_steps : 0);

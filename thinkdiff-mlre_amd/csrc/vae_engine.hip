@@ -273,6 +273,15 @@ int td_vae_init_random(td_vae* f, uint64_t seed, float std, void* stream) {
 // packed FLUX latents [ (h/2)(w/2), 4*latent_channels ] bf16 -> image.  h, w: latent height/width (image = 8h x 8w
 // for the 4-block FLUX VAE).  image_u8: [H, W, 3] uint8 (may be NULL); image_chw: bf16 [3, H, W] = vae.decode output
 // (may be NULL).  The z / scaling_factor + shift_factor step of the pipeline is applied first.
+// Image size td_vae_decode writes for an h x w latent: one 2x upsampler behind every block but the last, and the packed latent's channel count.
+int td_vae_output_shape(const td_vae* f, int h, int w, int* H, int* W, int* packed_channels) {
+  TD_CHECK_ARG(f && h > 0 && w > 0, "td_vae_output_shape: null context or empty latent");
+  if (H) *H = h << (f->nb - 1);
+  if (W) *W = w << (f->nb - 1);
+  if (packed_channels) *packed_channels = 4 * f->cfg.latent_channels;
+  return TD_OK;
+}
+
 int td_vae_decode(td_vae* f, const void* packed_latents, int h, int w, float scaling_factor, float shift_factor,
                   void* image_u8, void* image_chw, void* stream) {
   TD_CHECK_ARG(f && packed_latents && (image_u8 || image_chw), "td_vae_decode: null argument");

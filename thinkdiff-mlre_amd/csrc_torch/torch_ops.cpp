@@ -182,6 +182,79 @@ at::Tensor sample_top_p(const at::Tensor& logits, double temperature, double top
   return out;
 }
 
+// ---- the engines: the denoise loop itself goes through the dispatcher ----------------------------------------------------------------
+// An engine is a stateful C++ object behind the C ABI (weights, workspaces, prepared conditioning); the ops take its handle as an int (the
+// td_flux* / td_vae* value, as thinkdiff.models.* hold it) and check every tensor against what the prepared context expects.
+td_flux* flux_of(int64_t h) {
+  TORCH_CHECK(h != 0, "thinkdiff_hip: null FLUX engine handle");
+  return (td_flux*)(uintptr_t)h;
+}
+void check_latents(td_flux* f, const at::Tensor& x, const char* name) {
+  int si = 0, c = 0, n = 0;
+  ok(td_flux_prepared_shape(f, &si, nullptr, &c, &n));
+  check_rows(x, name);
+  TORCH_CHECK(si > 0 && n > 0, "thinkdiff_hip: the FLUX context has no condition / timesteps prepared");
+  TORCH_CHECK(x.dim() == 2 && x.is_contiguous() && x.size(0) == si && x.size(1) == c, "thinkdiff_hip: ", name, " must be contiguous [", si, ", ", c, "] bf16, got ", x.sizes());
+}
+// velocity = FluxTransformer2DModel.forward(latents) at prepared step `step`
+at::Tensor& flux_forward_(int64_t engine, const at::Tensor& latents, int64_t step, at::Tensor& velocity) {
+  td_flux* f = flux_of(engine);
+  check_latents(f, latents, "latents"); check_latents(f, velocity, "velocity"); same_device(velocity, "velocity", latents);
+  DeviceGuard guard(latents.device());
+  ok(td_flux_forward(f, latents.data_ptr(), (int)step, velocity.data_ptr(), stream_of(latents)));
+  return velocity;
+}
+// the whole Euler flow-matching loop in place: FluxPipeline.__call__'s denoising loop (transformer + scheduler.step per sigma)
+at::Tensor& flux_denoise_(int64_t engine, at::Tensor& latents, at::ArrayRef<double> sigmas) {
+  td_flux* f = flux_of(engine);
+  check_latents(f, latents, "latents");
+  TORCH_CHECK(sigmas.size() >= 2, "thinkdiff_hip::flux_denoise_: sigmas needs n + 1 >= 2 entries");
+  std::vector<float> sg(sigmas.begin(), sigmas.end());
+  DeviceGuard guard(latents.device());
+  ok(td_flux_denoise(f, latents.data_ptr(), sg.data(), (int)sg.size() - 1, stream_of(latents)));
+  return latents;
+}
+// the same for several prepared contexts (a parent and its forks) at once, context k on streams[k] (hipStream_t values)
+void flux_denoise_multi_(at::ArrayRef<int64_t> engines, at::TensorList latents, at::ArrayRef<double> sigmas, at::ArrayRef<int64_t> streams) {
+  TORCH_CHECK(!engines.empty() && engines.size() == latents.size() && engines.size() == streams.size(), "thinkdiff_hip::flux_denoise_multi_: one latent tensor and one stream per engine");
+  TORCH_CHECK(sigmas.size() >= 2, "thinkdiff_hip::flux_denoise_multi_: sigmas needs n + 1 >= 2 entries");
+  std::vector<td_flux*> fs; std::vector<void*> ls, ss;
+  for (size_t k = 0; k < engines.size(); ++k) {
+    fs.push_back(flux_of(engines[k]));
+    check_latents(fs.back(), latents[k], "latents[k]"); same_device(latents[k], "latents[k]", latents[0]);
+    ls.push_back(latents[k].data_ptr()); ss.push_back((void*)(uintptr_t)streams[k]);
+  }
+  std::vector<float> sg(sigmas.begin(), sigmas.end());
+  DeviceGuard guard(latents[0].device());
+  ok(td_flux_denoise_multi(fs.data(), ls.data(), (int)fs.size(), sg.data(), (int)sg.size() - 1, ss.data()));
+}
+// AutoencoderKL.decode + VaeImageProcessor.postprocess: packed latents [(h/2)(w/2), 4C] -> uint8 [H, W, 3] (8h x 8w for the FLUX.1 VAE)
+at::Tensor vae_decode_u8(int64_t engine, const at::Tensor& packed, int64_t h, int64_t w, double scaling_factor, double shift_factor) {
+  TORCH_CHECK(engine != 0, "thinkdiff_hip: null VAE engine handle");
+  check_rows(packed, "packed");
+  int H = 0, W = 0, pc = 0;
+  TORCH_CHECK(h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "thinkdiff_hip::vae_decode_u8: even latent height and width");
+  ok(td_vae_output_shape((const td_vae*)(uintptr_t)engine, (int)h, (int)w, &H, &W, &pc));
+  TORCH_CHECK(packed.dim() == 2 && packed.is_contiguous() && packed.size(0) == (h / 2) * (w / 2) && packed.size(1) == pc,
+              "thinkdiff_hip::vae_decode_u8: packed must be contiguous [(h/2)(w/2) = ", (h / 2) * (w / 2), ", ", pc, "] bf16, got ", packed.sizes());
+  DeviceGuard guard(packed.device());
+  at::Tensor img = at::empty({H, W, 3}, packed.options().dtype(at::kByte));
+  ok(td_vae_decode((td_vae*)(uintptr_t)engine, packed.data_ptr(), (int)h, (int)w, (float)scaling_factor, (float)shift_factor, img.data_ptr(), nullptr, stream_of(packed)));
+  return img;
+}
+// the joint attention with QK^T and P.V on the e4m3 MFMA (td_attention_fp8): q, k, v [S, >= H*128] bf16 views
+at::Tensor attention_fp8(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, int64_t H, double scale) {
+  check_rows(q, "q"); check_rows(k, "k"); check_rows(v, "v"); same_device(k, "k", q); same_device(v, "v", q);
+  TORCH_CHECK(q.dim() == 2 && k.dim() == 2 && v.dim() == 2 && H > 0 && q.size(1) >= H * 128 && k.size(1) >= H * 128 && v.size(1) >= H * 128 && k.size(0) == v.size(0) &&
+              k.stride(0) == v.stride(0), "thinkdiff_hip::attention_fp8: q [Sq, >= H*128], k / v [Skv, >= H*128] with equal row strides");
+  DeviceGuard guard(q.device());
+  at::Tensor out = at::empty({q.size(0), H * 128}, q.options());
+  at::Tensor ws = at::empty({(int64_t)td_attention_fp8_workspace_bytes((int)q.size(0), (int)k.size(0), (int)H)}, q.options().dtype(at::kByte));
+  ok(td_attention_fp8(q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), out.data_ptr(), out.stride(0), (int)q.size(0), (int)k.size(0), (int)H,
+                      (float)scale, ws.data_ptr(), stream_of(q)));
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(thinkdiff_hip, m) {
@@ -195,6 +268,11 @@ TORCH_LIBRARY(thinkdiff_hip, m) {
   m.def("flux_unpack_latents(Tensor packed, int C, int H, int W, float div, float add) -> Tensor");
   m.def("cls_avgpool2(Tensor tokens) -> Tensor");
   m.def("sample_top_p(Tensor logits, float temperature, float top_p, int seed, int offset) -> Tensor");
+  m.def("flux_forward_(int engine, Tensor latents, int step, Tensor(a!) velocity) -> Tensor(a!)");
+  m.def("flux_denoise_(int engine, Tensor(a!) latents, float[] sigmas) -> Tensor(a!)");
+  m.def("flux_denoise_multi_(int[] engines, Tensor(a!)[] latents, float[] sigmas, int[] streams) -> ()");
+  m.def("vae_decode_u8(int engine, Tensor packed, int h, int w, float scaling_factor, float shift_factor) -> Tensor");
+  m.def("attention_fp8(Tensor q, Tensor k, Tensor v, int H, float scale) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(thinkdiff_hip, CUDA, m) {
@@ -208,4 +286,9 @@ TORCH_LIBRARY_IMPL(thinkdiff_hip, CUDA, m) {
   m.impl("flux_unpack_latents", &flux_unpack_latents);
   m.impl("cls_avgpool2", &cls_avgpool2);
   m.impl("sample_top_p", &sample_top_p);
+  m.impl("flux_forward_", &flux_forward_);
+  m.impl("flux_denoise_", &flux_denoise_);
+  m.impl("flux_denoise_multi_", &flux_denoise_multi_);
+  m.impl("vae_decode_u8", &vae_decode_u8);
+  m.impl("attention_fp8", &attention_fp8);
 }

@@ -16,6 +16,9 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from .. import _hip
+from ..ops import register as _register_ops
+
+_OPS = _register_ops()      # torch.ops.thinkdiff_hip: the denoise loop is dispatched as custom ops over the C ABI (GPU kernels only, no fallback)
 
 
 @dataclasses.dataclass
@@ -85,12 +88,7 @@ class FluxTransformer2DModel:
     @staticmethod
     def denoise_multi(contexts, latents, sigmas: Sequence[float], streams):
         """td_flux_denoise for several prepared contexts at once, context k on streams[k] (torch.cuda.Stream)."""
-        n, c = len(sigmas) - 1, len(contexts)
-        arr = (ctypes.c_float * (n + 1))(*[float(s) for s in sigmas])
-        hs = (ctypes.c_void_p * c)(*[m._h.value for m in contexts])
-        ls = (ctypes.c_void_p * c)(*[x.data_ptr() for x in latents])
-        ss = (ctypes.c_void_p * c)(*[st.cuda_stream for st in streams])
-        _hip.check(contexts[0]._L.td_flux_denoise_multi(hs, ls, c, ctypes.cast(arr, ctypes.c_void_p), n, ss))
+        _OPS.flux_denoise_multi_([int(m._h.value) for m in contexts], list(latents), [float(s) for s in sigmas], [int(st.cuda_stream) for st in streams])
         return latents
 
     # ---- parameters ---------------------------------------------------------------------------------
@@ -190,16 +188,12 @@ class FluxTransformer2DModel:
         assert latents.dtype == torch.bfloat16 and latents.is_contiguous() and latents.shape == (self._n_img, self.config.in_channels)
         if out is None:
             out = torch.empty_like(latents)
-        _hip.check(self._L.td_flux_forward(self._h, _hip.ptr(latents), step, _hip.ptr(out), _hip.stream_ptr()))
-        return out
+        return _OPS.flux_forward_(int(self._h.value), latents, int(step), out)
 
     def denoise(self, latents, sigmas: Sequence[float]):
         """In-place Euler flow-matching loop over the prepared timesteps (len(sigmas) == n_steps + 1)."""
         assert latents.dtype == torch.bfloat16 and latents.is_contiguous() and latents.shape == (self._n_img, self.config.in_channels)
-        n = len(sigmas) - 1
-        arr = (ctypes.c_float * (n + 1))(*[float(s) for s in sigmas])
-        _hip.check(self._L.td_flux_denoise(self._h, _hip.ptr(latents), ctypes.cast(arr, ctypes.c_void_p), n, _hip.stream_ptr()))
-        return latents
+        return _OPS.flux_denoise_(int(self._h.value), latents, [float(s) for s in sigmas])
 
     # ---- per-launch HIP-event trace (bench.py roofline leg) ------------------------------------------
     TRACE_CATEGORIES = ("gemm_256x256", "gemm_other", "attention", "layernorm_modulate", "qk_rmsnorm_rope", "gemm_288x192")

@@ -10,6 +10,9 @@ from typing import Dict, Sequence
 import torch
 
 from .. import _hip
+from ..ops import register as _register_ops
+
+_OPS = _register_ops()      # torch.ops.thinkdiff_hip (the uint8 decode goes through it)
 
 
 @dataclasses.dataclass
@@ -99,15 +102,11 @@ class AutoencoderKLDecoder:
         | "pt" (bf16 [3,H,W], the raw vae.decode output)."""
         x = packed_latents.to(self.device, torch.bfloat16).contiguous()
         H, W = h * self.upscale, w * self.upscale
-        u8 = chw = None
         if output_type == "pt":
             chw = torch.empty(3, H, W, dtype=torch.bfloat16, device=self.device)
-        else:
-            u8 = torch.empty(H, W, 3, dtype=torch.uint8, device=self.device)
-        _hip.check(self._L.td_vae_decode(self._h, _hip.ptr(x), h, w, self.config.scaling_factor, self.config.shift_factor,
-                                         ctypes.c_void_p(u8.data_ptr()) if u8 is not None else None, _hip.ptr(chw), _hip.stream_ptr()))
-        if output_type == "pt":
+            _hip.check(self._L.td_vae_decode(self._h, _hip.ptr(x), h, w, self.config.scaling_factor, self.config.shift_factor, None, _hip.ptr(chw), _hip.stream_ptr()))
             return chw
+        u8 = _OPS.vae_decode_u8(int(self._h.value), x, int(h), int(w), float(self.config.scaling_factor), float(self.config.shift_factor))
         if output_type == "np":
             return u8
         from PIL import Image

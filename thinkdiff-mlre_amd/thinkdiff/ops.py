@@ -18,6 +18,11 @@ norm_rows                  LayerNorm / RMSNorm rows (+ adaLN modulation)
 qk_norm_rope_              per-head QK-RMSNorm + rotary embedding, in place
 euler_step_                FlowMatchEulerDiscreteScheduler.step, in place
 flux_pack_latents / flux_unpack_latents, cls_avgpool2, sample_top_p
+flux_forward_ / flux_denoise_ / flux_denoise_multi_   FluxTransformer2DModel.forward and the pipeline's denoising loop, on a prepared engine
+                           (`engine` = the td_flux* handle thinkdiff.models.flux_transformer holds); tensors are checked against the
+                           extents the prepared context expects (td_flux_prepared_shape)
+vae_decode_u8              AutoencoderKL.decode + VaeImageProcessor.postprocess on a td_vae* engine
+attention_fp8              the joint attention with QK^T / P.V on the e4m3 MFMA
 """
 import os
 
@@ -39,6 +44,11 @@ SCHEMAS = {
     "flux_unpack_latents": "(Tensor packed, int C, int H, int W, float div, float add) -> Tensor",
     "cls_avgpool2": "(Tensor tokens) -> Tensor",
     "sample_top_p": "(Tensor logits, float temperature, float top_p, int seed, int offset) -> Tensor",
+    "flux_forward_": "(int engine, Tensor latents, int step, Tensor(a!) velocity) -> Tensor(a!)",
+    "flux_denoise_": "(int engine, Tensor(a!) latents, float[] sigmas) -> Tensor(a!)",
+    "flux_denoise_multi_": "(int[] engines, Tensor(a!)[] latents, float[] sigmas, int[] streams) -> ()",
+    "vae_decode_u8": "(int engine, Tensor packed, int h, int w, float scaling_factor, float shift_factor) -> Tensor",
+    "attention_fp8": "(Tensor q, Tensor k, Tensor v, int H, float scale) -> Tensor",
 }
 
 _loaded = False
