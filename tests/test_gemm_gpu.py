@@ -132,6 +132,39 @@ def test_linear_grouped_two_problems(hip, M0, M1, N, K, cfg):
     _close(d1, _ref_linear(x1, w1, b1, gate=g1, res=h1))
 
 
+@pytest.mark.parametrize("cfg", [0, 3])
+@pytest.mark.parametrize("M,N,K", [(258, 768, 512), (2, 512, 256), (512 + 17, 1024, 1024), (576 + 64, 384, 256), (4354, 768, 384), (256 + 65, 512, 128)])
+def test_linear_ragged_last_tile(hip, M, N, K, cfg):
+    """The last row of tiles holds 1 ... 64 rows (config 5: 258 text rows = one 256-row tile + 2; 4 354 joint rows = 17 tiles + 2): those tiles
+    run the ragged loop (only the m-tiles that hold rows are multiplied), with either big tile shape; 65 rows stay on the main loop."""
+    g = torch.Generator().manual_seed(M * 3 + N + cfg)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    gate = torch.randn(N, generator=g).bfloat16()
+    h = torch.randn(M, N, generator=g).bfloat16()
+    y = h.cuda()
+    hip.linear_grouped2(x.cuda(), w.cuda(), b.cuda(), y, None, None, None, None, gate0=gate.cuda(), res0=y, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(x, w, b, gate=gate, res=h))
+
+
+@pytest.mark.parametrize("cfg", [0, 3])
+def test_linear_grouped_ragged_text_rows(hip, cfg):
+    """Config 5's double-stream shape in one grouped launch: 4096 image rows + 258 text rows (the text problem's second tile holds 2 rows)."""
+    M0, M1, N, K = 4096, 258, 768, 512
+    g = torch.Generator().manual_seed(cfg + 5)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()
+    x0, x1 = mk(M0, K), mk(M1, K)
+    w0, w1 = (mk(N, K).float() * 0.05).bfloat16(), (mk(N, K).float() * 0.05).bfloat16()
+    b0, b1 = mk(N), mk(N)
+    d0, d1 = torch.empty(M0, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M1, N, dtype=torch.bfloat16, device="cuda")
+    hip.linear_grouped2(x0.cuda(), w0.cuda(), b0.cuda(), d0, x1.cuda(), w1.cuda(), b1.cuda(), d1, act=1, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    _close(d0, _ref_linear(x0, w0, b0, act=1), 2.0 ** -6)
+    _close(d1, _ref_linear(x1, w1, b1, act=1), 2.0 ** -6)
+
+
 @pytest.mark.parametrize("M,N,K", [(4289, 3072, 1024), (449, 9216, 512), (100, 192, 64), (289, 200, 128)])
 def test_linear_tile_288x192(hip, M, N, K):
     g = torch.Generator().manual_seed(M + N)

@@ -29,7 +29,8 @@ def test_quant_rows_int8_bit_exact(hip):
     assert s[5] == 1.0 and not q[5].any() and int(q.abs().max()) == 127
 
 
-@pytest.mark.parametrize("M,N,K,cfg", [(4289, 3072, 3072, -1), (193, 768, 1024, -1), (777, 1536, 6144, 3), (20, 512, 256, 2), (1000, 9216, 3072, 0)])
+@pytest.mark.parametrize("M,N,K,cfg", [(4289, 3072, 3072, -1), (193, 768, 1024, -1), (777, 1536, 6144, 3), (20, 512, 256, 2), (1000, 9216, 3072, 0),
+                                       (258, 1024, 512, 0), (4354, 768, 1024, 0), (576 + 3, 768, 512, 3), (2, 512, 256, 0)])      # (ragged last tiles: csrc/gemm_bf16.hip)
 def test_linear_int8_matches_integer_contraction(hip, M, N, K, cfg):
     torch.manual_seed(M + N)
     x = torch.randn(M, K, device="cuda").bfloat16()

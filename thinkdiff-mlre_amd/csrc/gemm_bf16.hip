@@ -455,6 +455,53 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
       }
     }
   } else
+  if (WM >= 8 && !CONV && pv.M - m0 <= p.ragged_rows) {      // (the big tiles only: 64 rows are at most four m-tiles of the lower wave row, none of the upper)
+  // Ragged tile: at most 64 of the tile's rows exist (config 5's 258 text rows and 4 354 joint rows are whole 256-row tiles plus TWO rows:
+  // 5.6 % of that shape's tiles).  The staging protocol is the main loop's (same DMA instructions in the same order, same counted wait --
+  // every wave takes part), but only the m-tiles that hold rows are multiplied: the waves of the upper half have none, the others at most
+  // four, so the tile costs its operand traffic instead of a full tile of MFMAs on zeros.  Plain code: nothing here is matrix-bound.
+  const int mt_valid = wr == 0 ? (pv.M - m0 + 15) >> 4 : 0;      // wave-uniform
+#pragma unroll
+  for (int s = SA; s < NS; ++s) stage_one(s, 0, 1, min(1, nt - 1));
+  int wcur = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* wb = smem + W_REGION + wcur * W_BYTES + woff;
+    const char* ab = smem + (t & 1) * A_BYTES + aoff;
+    const int kt_a = min(t + 1, nt - 1), kt_w = min(t + 2, nt - 1);
+    const int abuf_next = (t + 1) & 1;
+    const int wbuf_next = wcur == 0 ? 2 : wcur - 1;
+    wcur = wcur == 2 ? 0 : wcur + 1;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) stage_one(s, abuf_next, wbuf_next, s < SA ? kt_a : kt_w);
+    if (mt_valid > 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int fo = foff0 ^ (ks << 6);
+        bf16x8_t wf[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + fo);
+#pragma unroll
+        for (int i = 0; i < (WM < 4 ? WM : 4); ++i) {
+          if (i < mt_valid) {
+            const bf16x8_t af = *(const bf16x8_t*)(ab + i * 16 * ROW_BYTES + fo);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              if constexpr (I8) {
+                typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+                acc[j][i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, wf[j]), __builtin_bit_cast(i32x4_t, af),
+                                                                                               __builtin_bit_cast(i32x4_t, acc[j][i]), 0, 0, 0));
+              } else {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[j][i], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  } else
   {
   // Main loop, one barrier per k-tile.  Inside a tile every instruction kind is spread through the MFMA
   // stream (pinned with sched_group_barrier, hipcc otherwise clusters them):
@@ -595,6 +642,7 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   p.tiles_m0 = (p.M + BM - 1) / BM;
   p.tiles_m = p.tiles_m0 + (p.g_M > 0 ? (p.g_M + BM - 1) / BM : 0);
   p.tiles_n = (p.N + BN - 1) / BN;
+  p.ragged_rows = getenv("TD_GEMM_NO_RAGGED") ? 0 : 64;      // (A/B switch of the ragged-tile loop; read per launch so one process can time both)
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   // the dynamic-LDS limit is a per-device function attribute: set it once per device (a process may drive several)
   static std::atomic<unsigned long long> attr_done{0ull};
