@@ -367,9 +367,10 @@ def side_workload(a, dist, rank, world, dev):
         res = {"metric": "images/sec (1024², 28 steps) ThinkDiff-CLIP FLUX.1 at 1/2/4/8 MI355X", "value": images / elapsed, "unit": "images/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None,
-               "dtype": {"bf16": "bf16", "fp8": FP8_DTYPE, "int8": INT8_DTYPE}[a.precision],
+               "dtype": {"bf16": "bf16", "fp8": FP8_DTYPE, "int8": INT8_DTYPE}[a.precision] + ("; joint attention QK^T / P.V on the e4m3 MFMA" if a.attention == "fp8" else ""),
                "data": "synthetic" if not a.dry_run else "none (dry run: stub pipeline on the CPU, gloo; the rate is meaningless)",
-               "config": {"workload": workload, "precision": a.precision, "images_per_rank_per_step": G if a.workload == "config2" else None,
+               "config": {"workload": workload, "precision": a.precision, "act_scales": a.act_scales if a.precision == "int8" else None, "attention": a.attention,
+                          "images_per_rank_per_step": G if a.workload == "config2" else None,
                           "prompts": a.prompts if a.workload == "config5" else None,
                           "parallelism": f"dp{world} (" + ("sharded job list" if a.workload == "config5" else "independent images, seed+rank") + ")"},
                "dry_run": bool(a.dry_run)}
@@ -391,11 +392,11 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="independent images advanced concurrently per rank (engine contexts on separate streams); a step = this many images")
     ap.add_argument("--precision", choices=("bf16", "fp8", "int8"), default=None,
-                    help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = BASELINE config 5's e4m3 path "
-                         "(the default of --workload config5)")
-    ap.add_argument("--act-scales", choices=("dynamic", "history"), default="dynamic",
+                    help="operand type of the block GEMMs; bf16 = the headline (reference precision), fp8 = e4m3, int8 = symmetric W8A8 "
+                         "(--workload config5 defaults to int8 + --act-scales history + --attention fp8: the 8-bit policy inside the 1e-2 pixel bar)")
+    ap.add_argument("--act-scales", choices=("dynamic", "history"), default=None,
                     help="--precision int8 only: per-token activation scales measured on the spot, or taken from the previous denoise step (td_flux_set_act_scales)")
-    ap.add_argument("--attention", choices=("bf16", "fp8"), default="bf16",
+    ap.add_argument("--attention", choices=("bf16", "fp8"), default=None,
                     help="arithmetic of the joint attention: bf16 = the reference graph's (headline), fp8 = QK^T / P.V on the e4m3 MFMA "
                          "(td_flux_set_attention; meant for the 8-bit precisions)")
     ap.add_argument("--no-fp8-leg", action="store_true",
@@ -409,8 +410,15 @@ def main():
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 1 if a.workload == "config5" else 3
-    if a.precision is None:
-        a.precision = "fp8" if a.workload == "config5" else "bf16"
+    if a.precision is None and a.workload == "config5":
+        # BASELINE config 5 names the 8-bit MFMA path; its default here is the 8-bit policy that holds the reference tolerance (6.4e-3 pixel RMSE
+        # against the 28-step oracle fixture): int8 block Linears under history scales + the e4m3 joint attention.  `--precision fp8` = all-e4m3 Linears (1.7e-2).
+        a.precision = "int8"
+        a.act_scales = a.act_scales or "history"
+        a.attention = a.attention or "fp8"
+    a.precision = a.precision or "bf16"
+    a.act_scales = a.act_scales or "dynamic"
+    a.attention = a.attention or "bf16"
 
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))      # BEFORE anything touches the GPU in this process

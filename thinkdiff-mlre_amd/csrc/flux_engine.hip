@@ -87,7 +87,6 @@ struct td_flux {
   int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
   int attn_mode = 0;                        // parent: TD_ATTENTION_BF16 / TD_ATTENTION_FP8 (td_flux_set_attention)
   char* attn8_ws = nullptr;                 // packed e4m3 q | k | v^T of the 8-bit attention (per context)
-  const TdQkRopeParams* fuse_rope = nullptr; // set around an attn() call whose pack pass applies QK-norm + RoPE itself (8-bit attention)
   std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
   // int8 with history scales (td_flux_set_act_scales): per (block tensor, token) the scale / inverse scale of THIS step, taken from the maxima the
@@ -225,15 +224,16 @@ int qk_rope(td_flux* f, hipStream_t s, const TdQkRopeParams& p) {
   TraceScope ts(f, s, TD_TRACE_QKROPE, 0.0);
   return td_qk_norm_rope_launch(p, s);
 }
-int attn(td_flux* f, hipStream_t s, const TdAttnParams& p) {
+// rope != null: the 8-bit attention's pack pass applies QK-RMSNorm + RoPE itself (the block loop skipped td_qk_norm_rope)
+int attn(td_flux* f, hipStream_t s, const TdAttnParams& p, const TdQkRopeParams* rope = nullptr) {
   TraceScope ts(f, s, TD_TRACE_ATTN, 4.0 * p.Sq * (double)p.Skv * p.Hq * 128.0);
   const td_flux* root = f->parent ? f->parent : f;
   if (root->attn_mode == TD_ATTENTION_FP8) {      // both products on the e4m3 MFMA: pack pass + persistent kernel (csrc/attention_fp8.hip)
     TdAttnParams q = p;
     q.f8_ws = f->attn8_ws;
     q.variant = p.variant & 0x1000;
-    if (f->fuse_rope) {      // QK-RMSNorm + RoPE inside the pack pass (the block loop skipped td_qk_norm_rope)
-      const TdQkRopeParams& r = *f->fuse_rope;
+    if (rope) {
+      const TdQkRopeParams& r = *rope;
       q.rope_cos = r.cos; q.rope_sin = r.sin; q.rope_split = r.split; q.rope_eps = r.eps; q.rope_q_premul = r.q_premul;
       q.rope_wqA = r.wqA; q.rope_wkA = r.wkA; q.rope_wqB = r.wqB; q.rope_wkB = r.wkB;
     }
@@ -700,7 +700,6 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
   // 8-bit attention: its pack pass reads the raw projections and applies QK-norm + RoPE itself (bit-identical, one HBM round trip less)
   const bool rope_in_pack = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_FUSE") == nullptr;      // (the switch: A/B timing and the bit-identity test)
-  f->fuse_rope = rope_in_pack ? &rp : nullptr;
   const int q_int8 = root->precision == TD_PRECISION_INT8;
   // the LayerNorm ahead of an fp8 Linear writes e4m3 rows + scales, ahead of a bf16 one the bf16 rows
   // history scales (int8): this step quantises the MLP operands under the scales the previous step's maxima give
@@ -738,7 +737,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     float* asc_o = f->hs_scale + (size_t)(L + Ls + i) * f->hs_cap;
     unsigned* aam_o = f->hs_amax + (size_t)(L + Ls + i) * f->hs_cap;
     if (ao_hist) { ap.q8 = f->aq; ap.ldq8 = D; ap.q8_inv = f->hs_inv + (size_t)(L + Ls + i) * f->hs_cap; ap.q8_amax = aam_o; }
-    TD_TRY(attn(f, s, ap));
+    TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr));
     ap.q8 = nullptr;
     if (m8 & TD_FP8_OUT) {
       const DoubleW8& w8 = root->dbl8[i];
@@ -819,7 +818,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     if (!rope_in_pack) TD_TRY(qk_rope(f, s, rp));
     ap.O = f->cat; ap.ldo = D + M;
     if (sg_hist) { ap.q8 = f->aq; ap.ldq8 = D + M; ap.q8_inv = hiv; ap.q8_amax = ham; }   // the attention half of [attn | mlp] as int8, same per-token scale
-    TD_TRY(attn(f, s, ap));
+    TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr));
     ap.q8 = nullptr;
     if (m8 & TD_FP8_SINGLE_OUT) {
       if (sg_hist) {
@@ -842,7 +841,6 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   TD_TRY(norm_rows(f, s, nf));
   TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
   if (hist_mode) { f->hs_step = step; f->hs_T = T; f->hs_S = S; } else f->hs_step = -1;
-  f->fuse_rope = nullptr;
   return TD_OK;
 }
 
