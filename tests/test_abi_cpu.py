@@ -39,6 +39,30 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == 2 and b"K=40" in lib.td_last_error()
 
 
+def test_round3_entry_points_refuse_bad_arguments_without_a_gpu():
+    """td_attention_fp8 / td_attention_fp8_qk_rope / td_flux_prepared_shape / td_vae_output_shape: argument errors come back as TD_ERR_INVALID
+    before any HIP call."""
+    lib = ctypes.CDLL(LIB)
+    lib.td_last_error.restype = ctypes.c_char_p
+    one = ctypes.c_void_p(256)                          # never dereferenced
+    i64, f32 = ctypes.c_int64, ctypes.c_float
+    # head blocks that do not fit a row: 3 x 24 x 128 columns need ld >= 9216
+    rc = lib.td_attention_fp8_qk_rope(one, i64(4096), 0, 3072, 6144, one, i64(3072), 100, 24, one, one, 0, None, None, None, None, f32(1e-6), f32(0.088), one, None)
+    assert rc == 2 and b"do not fit" in lib.td_last_error()
+    # missing rotary tables
+    rc = lib.td_attention_fp8_qk_rope(one, i64(9216), 0, 3072, 6144, one, i64(3072), 100, 24, None, None, 0, None, None, None, None, f32(1e-6), f32(0.088), one, None)
+    assert rc == 2
+    # two batch entries / Hq != Hkv do not exist for the 8-bit attention; no workspace
+    rc = lib.td_attention_fp8(one, i64(3072), one, one, i64(3072), one, i64(3072), 64, 64, 24, f32(0.088), None, None)
+    assert rc == 2 and b"workspace" in lib.td_last_error()
+    rc = lib.td_attention_fp8(one, i64(3070), one, one, i64(3072), one, i64(3072), 64, 64, 24, f32(0.088), one, None)
+    assert rc == 2 and b"16-byte" in lib.td_last_error()
+    lib.td_attention_fp8_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.td_attention_fp8_workspace_bytes(0, 64, 24) == 0 and lib.td_attention_fp8_workspace_bytes(4289, 4289, 24) > 3 * 4289 * 24 * 128
+    assert lib.td_flux_prepared_shape(None, None, None, None, None) == 2
+    assert lib.td_vae_output_shape(None, 8, 8, None, None, None) == 2
+
+
 def test_oversize_element_counts_are_refused_not_truncated():
     """A dispatch carries 32-bit work-item counts; grid x block >= 2^32 used to be truncated silently (round 2: the synthetic
     checkpoint filled only its first 3.3 G elements).  Every launcher that sizes its grid from an element count now goes through

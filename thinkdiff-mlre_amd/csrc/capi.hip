@@ -111,6 +111,8 @@ int td_attention_fp8_qk_rope(const void* qkv, int64_t ld, int q_col, int k_col, 
                              const float* cos, const float* sin, int split, const void* wqA, const void* wkA, const void* wqB, const void* wkB,
                              float eps, float scale, void* workspace, void* stream) {
   TD_CHECK_ARG(qkv && cos && sin && q_col >= 0 && k_col >= 0 && v_col >= 0 && (q_col | k_col | v_col) % 8 == 0, "td_attention_fp8_qk_rope: projection buffer, both tables, 16-byte aligned column offsets");
+  TD_CHECK_ARG(S > 0 && H > 0 && (long long)(q_col > k_col ? (q_col > v_col ? q_col : v_col) : (k_col > v_col ? k_col : v_col)) + (long long)H * 128 <= ld,
+               "td_attention_fp8_qk_rope: the q / k / v head blocks (H=%d x 128 columns from their offsets) do not fit a row of ld=%lld", H, (long long)ld);
   TdAttnParams p;
   p.Q = (const bf16_t*)qkv + q_col; p.K = (const bf16_t*)qkv + k_col; p.V = (const bf16_t*)qkv + v_col; p.O = (bf16_t*)o;
   p.batch = 1; p.Sq = S; p.Skv = S; p.Hq = H; p.Hkv = H; p.head_dim = 128;
