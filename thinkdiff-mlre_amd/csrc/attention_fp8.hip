@@ -235,7 +235,9 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
 // which the row sum -- taken over the same bytes -- cancels; 1.9 % rms remains, less than e4m3's own rounding of a probability).
 // It replaces 32 v_exp_f32 (8 issue cycles each) + 16 v_cvt_pk_fp8_f32 per tile and wave by 32 4-cycle conversions: the exp form
 // of this kernel is VALU-bound (rocprofv3: MFMA 35 %, VALU 61 % of the cycles, not overlapping), this one is not.
-template <int NWAVES, bool XCD_REMAP, bool LIN>
+// PROBE (-DTD_ATTN8_PROBE builds only; results are WRONG, the launch duration is the measurement): 1 no row-maximum chain, 2 no reference logic at
+// all, 3 probabilities not converted (the P.V MFMAs no longer wait for the scores), 4 no score MFMAs, 5 no P.V MFMAs, 6 no tile barrier.
+template <int NWAVES, bool XCD_REMAP, bool LIN, int PROBE = 0>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(const TdAttnParams p, const char* __restrict__ pk, const F8Layout lay,
                                                                                char* __restrict__ ws, const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       // my pieces of tile t+1 landed (tile t+2 may still be in flight); after the barrier everyone's are visible and slot FREE
       // (tile t-1) has no reader left
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMOPS) : "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (PROBE != 6) __builtin_amdgcn_s_barrier();
       const int ksc = (int)ksc_r[SLOT], vsc = (int)vsc_r[SLOT];
 
       // ---- S^T - ref = K8 . Q8^T - ref ------------------------------------------------------------------------------------
@@ -369,6 +371,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
         return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
       };
       // four MFMAs, the V^T fragments of this tile read in their shadow (into the registers the K fragments leave)
+      if constexpr (PROBE == 4) {
+        st[0] = negm; st[1] = negm;
+        vf[0] = vread(0); vf[1] = vread(1); vf[2] = vread(2); vf[3] = vread(3);
+      } else {
       st[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[0], qf[0], negm, 0, 0, 0, ksc, 0, (int)qsc);
       vf[0] = vread(0);
       st[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[2], qf[0], negm, 0, 0, 1, ksc, 0, (int)qsc);
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       vf[2] = vread(2);
       st[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[3], qf[1], st[1], 0, 0, 1, ksc, 0, (int)qsc);
       vf[3] = vread(3);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -399,10 +406,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       // MFMA result needs.  The inline-asm v_max3 alone is invisible to its hazard recogniser and read registers the matrix pipe
       // had not written yet (a row maximum that missed elements -> a probability past 448 -> NaN, about one row in 600).
       float mx = fmaxf(st[0][15], st[1][15]);
+      if constexpr (PROBE != 1 && PROBE != 2) {
 #pragma unroll
-      for (int rr = 0; rr < 15; ++rr) mx = max3(mx, st[0][rr], st[1][rr]);
-      mx = half_swap_max(mx);
-      const bool first = t == kb;
+        for (int rr = 0; rr < 15; ++rr) mx = max3(mx, st[0][rr], st[1][rr]);
+        mx = half_swap_max(mx);
+      }
+      if constexpr (PROBE == 2) mx = 0.f;
+      const bool first = PROBE == 2 ? false : t == kb;
       constexpr float LIMIT = LIN ? 8.f * REF_LIMIT + 56.f : REF_LIMIT;      // (LIN: 126, the byte of 448)
       if (first || __any(mx > LIMIT)) {
         const float xm = LIN ? (mx - 56.f) * 0.125f : mx;                                   // the row maximum in log2 units above the reference
@@ -445,16 +455,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
           }
         }
 
+      if constexpr (PROBE == 3) pf = qf[0];
       // ---- O^T += V8^T . P^T, row sums as one more row-block of ones; the next tile's K fragments under these MFMAs ---------
       lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf, lacc, 0, 0, 0, 127, 0, 127);
       stage(FREE{}, t + 3);
-      o[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pf, o[0], 0, 0, 0, vsc, 0, 127);
+      if constexpr (PROBE != 5) o[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pf, o[0], 0, 0, 0, vsc, 0, 127);
       kf[0] = kread(NEXT{}, 0, 0);
-      o[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pf, o[1], 0, 0, 0, vsc, 0, 127);
+      if constexpr (PROBE != 5) o[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pf, o[1], 0, 0, 0, vsc, 0, 127);
       kf[2] = kread(NEXT{}, 1, 0);
-      o[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pf, o[2], 0, 0, 0, vsc, 0, 127);
+      if constexpr (PROBE != 5) o[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pf, o[2], 0, 0, 0, vsc, 0, 127);
       kf[1] = kread(NEXT{}, 0, 1);
-      o[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pf, o[3], 0, 0, 0, vsc, 0, 127);
+      if constexpr (PROBE != 5) o[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pf, o[3], 0, 0, 0, vsc, 0, 127);
       kf[3] = kread(NEXT{}, 1, 1);
       // MFMA | the stage's vector-memory operations, spread | MFMA | ... ; the next tile's K fragments under the last three
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -583,6 +594,18 @@ int td_attn_fp8_launch(const TdAttnParams& p, hipStream_t stream) {
     return 0;
   };
   int rc;
+#ifdef TD_ATTN8_PROBE
+  static std::atomic<unsigned long long> pdone[7] = {};
+  switch ((p.variant >> 16) & 7) {
+    case 1: return go(td_attn_fwd_d128_fp8_kernel<8, true, true, 1>, pdone[1], 512);
+    case 2: return go(td_attn_fwd_d128_fp8_kernel<8, true, true, 2>, pdone[2], 512);
+    case 3: return go(td_attn_fwd_d128_fp8_kernel<8, true, true, 3>, pdone[3], 512);
+    case 4: return go(td_attn_fwd_d128_fp8_kernel<8, true, true, 4>, pdone[4], 512);
+    case 5: return go(td_attn_fwd_d128_fp8_kernel<8, true, true, 5>, pdone[5], 512);
+    case 6: return go(td_attn_fwd_d128_fp8_kernel<8, true, true, 6>, pdone[6], 512);
+    default: break;
+  }
+#endif
   if (NW == 8) rc = lin ? go(td_attn_fwd_d128_fp8_kernel<8, true, true>, done[0], 512) : go(td_attn_fwd_d128_fp8_kernel<8, true, false>, done[1], 512);
   else rc = lin ? go(td_attn_fwd_d128_fp8_kernel<4, true, true>, done[2], 256) : go(td_attn_fwd_d128_fp8_kernel<4, true, false>, done[3], 256);
   if (rc) return rc;
