@@ -237,12 +237,7 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
 // of this kernel is VALU-bound (rocprofv3: MFMA 35 %, VALU 61 % of the cycles, not overlapping), this one is not.
 // PROBE (-DTD_ATTN8_PROBE builds only; results are WRONG, the launch duration is the measurement): 1 no row-maximum chain, 2 no reference logic at
 // all, 3 probabilities not converted (the P.V MFMAs no longer wait for the scores), 4 no score MFMAs, 5 no P.V MFMAs, 6 no tile barrier.
-// SPEC (LIN only): the scores of the tile's first 32 keys are finished before those of the second 32 are started, and their row maximum and
-// conversion run in the shadow of the second half's MFMAs -- SPECULATIVELY under the reference point in force; the branch on the row maximum
-// then sits behind the conversions instead of in front of them, and where it fires (first tile of a part, a probability about to leave e4m3's
-// range: a few per cent of the tiles) the plain path runs on the scores, which are kept alive until then (8 registers more: the words of P
-// cannot overwrite them).  Same bytes as the plain form: the speculative result is used only where the plain form would have computed exactly it.
-template <int NWAVES, bool XCD_REMAP, bool LIN, int PROBE = 0, bool SPEC = false>
+template <int NWAVES, bool XCD_REMAP, bool LIN, int PROBE = 0>
 __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(const TdAttnParams p, const char* __restrict__ pk, const F8Layout lay,
                                                                                char* __restrict__ ws, const int n_qblk, const int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -419,39 +414,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) negm[rr] = LIN ? 56.f - 8.f * m_run : -m_run;
       };
-      if constexpr (SPEC) {
-        static_assert(!SPEC || (LIN && PROBE == 0), "the speculative form exists for the integer-conversion probabilities");
-        st[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[0], qf[0], negm, 0, 0, 0, ksc, 0, (int)qsc);
-        vf[0] = vread(0);
-        st[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[1], qf[1], st[0], 0, 0, 0, ksc, 0, (int)qsc);
-        vf[1] = vread(1);
-        st[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[2], qf[0], negm, 0, 0, 1, ksc, 0, (int)qsc);
-        vf[2] = vread(2);
-        st[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[3], qf[1], st[1], 0, 0, 1, ksc, 0, (int)qsc);
-        vf[3] = vread(3);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        const bool last = key0 + KV_TILE > Skv;
-        if (last) mask_tail();
-        // (the first read of each accumulator is one the compiler can see: it places the wait states; see the plain form below)
-        float mxa = fmaxf(st[0][15], st[0][14]);
-#pragma unroll
-        for (int rr = 0; rr < 14; rr += 2) mxa = max3(mxa, st[0][rr], st[0][rr + 1]);
-        convert(0, pf);
-        float mxb = fmaxf(st[1][15], st[1][14]);
-#pragma unroll
-        for (int rr = 0; rr < 14; rr += 2) mxb = max3(mxb, st[1][rr], st[1][rr + 1]);
-        convert(1, pf);
-        const float mx = half_swap_max(fmaxf(mxa, mxb));
-        if (first || __any(mx > LIMIT)) {      // rare: the plain path on the scores, which are still alive (the 8 words of P are separate registers)
-          move_reference(mx);
-          convert(0, pf);
-          convert(1, pf);
-        }
-      } else {
       // four MFMAs, the V^T fragments of this tile read in their shadow (into the registers the K fragments leave)
       if constexpr (PROBE == 4) {
         st[0] = negm; st[1] = negm;
@@ -502,7 +464,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
             pf[kk * 4 + g] = wv;
           }
       }
-      }      // (!SPEC)
 
       if constexpr (PROBE == 3) pf = qf[0];
       // ---- O^T += V8^T . P^T, row sums as one more row-block of ones; the next tile's K fragments under these MFMAs ---------
@@ -643,12 +604,6 @@ int td_attn_fp8_launch(const TdAttnParams& p, hipStream_t stream) {
     return 0;
   };
   int rc;
-  if (NW == 8 && lin && (p.variant & 0x8000)) {      // A/B: the speculative-conversion form
-    static std::atomic<unsigned long long> sdone{0};
-    if (int e = go(td_attn_fwd_d128_fp8_kernel<8, true, true, 0, true>, sdone, 512)) return e;
-    TD_CHECK_LAUNCH();
-    return 0;
-  }
 #ifdef TD_ATTN8_PROBE
   static std::atomic<unsigned long long> pdone[7] = {};
   switch ((p.variant >> 16) & 7) {

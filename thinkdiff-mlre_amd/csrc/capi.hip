@@ -103,7 +103,7 @@ int td_attention_fp8(const void* q, int64_t ldq, const void* k, const void* v, i
   TdAttnParams p;
   p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o;
   p.batch = 1; p.Sq = Sq; p.Skv = Skv; p.Hq = Hq; p.Hkv = Hq; p.head_dim = 128;
-  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo; p.scale = scale; p.f8_ws = workspace; p.variant = ((g_attn_variant & 1) ? 0x1000 : 0) | ((g_attn_variant & 2) ? 0x2000 : 0) | ((g_attn_variant & 8) ? 0x8000 : 0) | (((g_attn_variant >> 4) & 7) << 16);      // td_attention_set_variant bit 0: the 4-wave A/B form, bit 1: exp2 probabilities, bit 3: speculative conversion, bits 4-6: timing-only probes (TD_ATTN8_PROBE builds)
+  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo; p.scale = scale; p.f8_ws = workspace; p.variant = ((g_attn_variant & 1) ? 0x1000 : 0) | ((g_attn_variant & 2) ? 0x2000 : 0) | (((g_attn_variant >> 4) & 7) << 16);      // td_attention_set_variant bit 0: the 4-wave A/B form, bit 1: exp2 probabilities, bits 4-6: timing-only probes (TD_ATTN8_PROBE builds)
   return td_attn_fp8_launch(p, (hipStream_t)stream);
 }
 

@@ -231,7 +231,7 @@ int attn(td_flux* f, hipStream_t s, const TdAttnParams& p, const TdQkRopeParams*
   if (root->attn_mode == TD_ATTENTION_FP8) {      // both products on the e4m3 MFMA: pack pass + persistent kernel (csrc/attention_fp8.hip)
     TdAttnParams q = p;
     q.f8_ws = f->attn8_ws;
-    q.variant = p.variant & (0x1000 | 0x8000);      // (A/B switches of the 8-bit kernel: TD_ATTN_TUNE)
+    q.variant = p.variant & 0x1000;
     if (rope) {
       const TdQkRopeParams& r = *rope;
       q.rope_cos = r.cos; q.rope_sin = r.sin; q.rope_split = r.split; q.rope_eps = r.eps; q.rope_q_premul = r.q_premul;

@@ -294,11 +294,11 @@ def bench_attn8():
             st["i"] = (st["i"] + 1) % len(pool)
             q = pool[st["i"]]
             _hip.attention_fp8(q[:, :W], q[:, W:2 * W], q[:, 2 * W:], out, H, workspace=ws)
-        best = {"bf16": 1e9, "fp8": 1e9, "fp8-4wave": 1e9, "fp8-exp2": 1e9, "fp8-4wave-exp2": 1e9, "fp8-spec": 1e9}
+        best = {"bf16": 1e9, "fp8": 1e9, "fp8-4wave": 1e9, "fp8-exp2": 1e9, "fp8-4wave-exp2": 1e9}
         for _ in range(5):
             best["bf16"] = min(best["bf16"], timeit(f16, iters=10, warmup=2))
             best["fp8"] = min(best["fp8"], timeit(f8, iters=10, warmup=2))
-            for var, name in ((1, "fp8-4wave"), (2, "fp8-exp2"), (3, "fp8-4wave-exp2"), (8, "fp8-spec")):
+            for var, name in ((1, "fp8-4wave"), (2, "fp8-exp2"), (3, "fp8-4wave-exp2")):
                 L.td_attention_set_variant(var)
                 best[name] = min(best[name], timeit(f8, iters=10, warmup=2))
             L.td_attention_set_variant(0)
