@@ -213,14 +213,16 @@ def _heads(x, H):
 
 # 8-bit attention mode (restates csrc/attention_fp8.hip, the attention of td_flux_set_attention(TD_ATTENTION_FP8)): q (times
 # scale x log2 e), k and v go to OCP e4m3 under power-of-two (E8M0) scales -- q and k per (token, head), v per (64-key tile,
-# head) -- the scores accumulate exactly, P = exp2(s - ceil(rowmax) + 7) is rounded to e4m3 (an integer reference: the rounding of a
-# probability does not depend on how the kernel tiles the keys), the row sum is taken over the rounded P,
-# O = P.V accumulates exactly.  Off by default: the reference has no such path.
-# The probabilities: "linear" (the shipped kernel) -- the e4m3 BYTE is rne(8 (s - ceil(rowmax)) + 112) clamped to [0, 126], i.e.
+# head) -- the scores accumulate exactly, P = exp2(s - ceil(rowmax) + h) is rounded to e4m3 (an integer reference: the rounding of a
+# probability does not depend on how the kernel tiles the keys; h = FP8_ATTENTION_HEADROOM = the kernel's REF_HEADROOM: the row maximum
+# lands in (2^(h-1), 2^h] of e4m3's range), the row sum is taken over the rounded P, O = P.V accumulates exactly.  Off by default: the
+# reference has no such path.
+# The probabilities: "linear" (the shipped kernel) -- the e4m3 BYTE is rne(8 (s - ceil(rowmax) + h) + 56) clamped to [0, 126], i.e.
 # 2^floor(x) (1 + frac(x)) with 3 mantissa bits instead of 2^x (an e4m3 byte read as an integer is a piecewise-linear log2 scale);
-# "exp2" -- P = exp2(s - ceil(rowmax) + 7) rounded to e4m3 (the kernel's A/B form).
+# "exp2" -- P = exp2(s - ceil(rowmax) + h) rounded to e4m3 (the kernel's A/B form).
 FP8_ATTENTION = False
 FP8_ATTENTION_PROB = "linear"
+FP8_ATTENTION_HEADROOM = 5.0
 
 
 def _e8m0_quant(x, dims):
@@ -248,11 +250,11 @@ def _attention_fp8(q, k, v):
             v8, sv = _e8m0_quant(vg, (1, 2))
             vq = (v8 * sv).view(-1, hd)[:Skv]
             s = (q8 * sq) @ (k8 * sk).T
-            ref = torch.ceil(s.amax(dim=1, keepdim=True))
+            ref = torch.ceil(s.amax(dim=1, keepdim=True)) - FP8_ATTENTION_HEADROOM      # the row maximum lands in (2^(h-1), 2^h] of e4m3's range
             if FP8_ATTENTION_PROB == "linear":
-                p = torch.round(8.0 * (s - ref) + 112.0).clamp_(0, 126).to(torch.uint8).view(torch.float8_e4m3fn).float()
+                p = torch.round(8.0 * (s - ref) + 56.0).clamp_(0, 126).to(torch.uint8).view(torch.float8_e4m3fn).float()
             else:
-                p = torch.exp2(s - ref + 7.0).to(torch.float8_e4m3fn).float()
+                p = torch.exp2(s - ref).to(torch.float8_e4m3fn).float()
             out[b, :, h * hd:(h + 1) * hd] = ((p @ vq) / p.sum(dim=1, keepdim=True)).to(q.dtype)
     return out
 
