@@ -187,6 +187,36 @@ def _rel_close(a, b, tol=2.0 ** -7):
     return bool((a - b).abs().max() <= tol * b.abs().max())
 
 
+@pytest.mark.parametrize("S,H", [(449, 4), (4289, 24), (1000, 80)])
+def test_fixed_reference_point_form(hip, S, H):
+    """td_attention_joint_prescaled_bf16 with a score bound: the softmax runs against that constant instead of a running row maximum (what the FLUX
+    engine does with the bound its QK-RMSNorm weights give).  Same answer as the running-maximum form to the bf16 rounding of the probabilities,
+    whether the bound is the Cauchy-Schwarz one, 30 octaves too high, or too LOW by two octaves (a score above it is harmless)."""
+    g = torch.Generator().manual_seed(S * 5 + H)
+    qkv = torch.randn(S, 3 * H * 128, generator=g).bfloat16()
+    c = (128 ** -0.5) * 1.4426950408889634
+    qkv[:, :H * 128] = (qkv[:, :H * 128].float() * c).bfloat16()
+    d = qkv.cuda()
+    q, k, v = d[:, :H * 128], d[:, H * 128:2 * H * 128], d[:, 2 * H * 128:]
+    qh, kh = qkv[:, :H * 128].float().view(S, H, 128), qkv[:, H * 128:2 * H * 128].float().view(S, H, 128)
+    cs = float((qh.norm(dim=2).amax() * kh.norm(dim=2).amax()))              # Cauchy-Schwarz over all rows and heads
+    smax = max(float((qh[:, h] @ kh[:, h].T).amax()) for h in ([0, H - 1] if H > 4 else range(H)))
+    base = hip.attention_joint_prescaled(q, k, v, torch.zeros(S, H * 128, dtype=torch.bfloat16, device="cuda"), H, 0.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(base.float()).all()
+    for bound in (cs, cs + 30.0, max(smax - 2.0, 0.5)):
+        out = hip.attention_joint_prescaled(q, k, v, torch.zeros(S, H * 128, dtype=torch.bfloat16, device="cuda"), H, bound)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        _check(out, base.float().cpu(), 2.0 ** -7)
+    hs = [0, H - 1] if H > 4 else list(range(H))
+    for h in hs:
+        ref = torch.softmax((qh[:, h] @ kh[:, h].T) * math.log(2.0), dim=-1) @ qkv[:, (2 * H + h) * 128:(2 * H + h + 1) * 128].float()
+        _check(out[:, h * 128:(h + 1) * 128], ref)
+    with pytest.raises(hip.ThinkDiffHipError):
+        hip.attention_joint_prescaled(q, k, v, torch.zeros(S, H * 128, dtype=torch.bfloat16, device="cuda"), H, float("inf"))
+
+
 @pytest.mark.parametrize("S,H", [(449, 4), (4289, 24), (4354, 24)])
 def test_prescaled_q_form(hip, S, H):
     """The form the FLUX engine uses: q arrives multiplied by scale * log2(e) (rounded to bf16 once, where RoPE rounds it), the

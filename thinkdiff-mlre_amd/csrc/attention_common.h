@@ -107,10 +107,14 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
 // zero and m_run is 0: the reference point is set to the tile's row maximum whatever it is.
 // RS: row sums on the matrix pipe (lacc); otherwise they are added on the VALU into lacc[0] as HALF sums (the caller adds the
 // two lane halves at the end) -- the A/B of which pipe has room on a given shape.
-template <unsigned PO, bool PRE, bool RS = true>
+// FIXED: the reference point is a constant the caller knows to bound every score (TdAttnParams::score_bound; m_run and qnegm hold it from the
+// start): no row maximum, no branch, no rescale -- a bf16 probability keeps its 8 mantissa bits at any magnitude and the sums are fp32, so the
+// reference only has to keep exp2(s - ref) inside the floating-point range, not near 1.
+template <unsigned PO, bool PRE, bool RS = true, bool FIXED = false>
 __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t (&o)[4], f32x16_t& lacc, float& m_run, bf16x8_t& qnegm,
                                                      const bool first, const float c, const unsigned (&va)[2][4], const int h5) {
   const float cc = PRE ? 1.0f : c;
+  if constexpr (!FIXED) {
   float mx = st[0][0];
 #pragma unroll
   for (int r = 0; r < 16; ++r) mx = max3(mx, st[0][r], st[1][r]);
@@ -139,6 +143,7 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
     m_run = m_new;
     qnegm[0] = h5 == 0 ? (short)f2bf(-m_new) : (short)0;
   }
+  }      // (!FIXED)
   bf16x8_t pf[2][2];
   float psum = 0.f;
 #pragma unroll

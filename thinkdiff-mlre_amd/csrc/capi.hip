@@ -96,6 +96,15 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
   return td_attn_launch(p, (hipStream_t)stream);
 }
 
+int td_attention_joint_prescaled_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo, int S, int H, float score_bound, void* stream) {
+  TdAttnParams p;
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o;
+  p.batch = 1; p.Sq = S; p.Skv = S; p.Hq = H; p.Hkv = H; p.head_dim = 128;
+  p.ldq = (int)ldq; p.ldkv = (int)ldkv; p.ldo = (int)ldo; p.scale = 1.0f; p.causal = 0; p.causal_offset = 0; p.variant = g_attn_variant & 0xff;
+  p.q_prescaled = 1; p.score_bound = score_bound;
+  return td_attn_launch(p, (hipStream_t)stream);
+}
+
 size_t td_attention_fp8_workspace_bytes(int Sq, int Skv, int Hq) { return Sq > 0 && Skv > 0 && Hq > 0 ? td_attn_fp8_ws_bytes(Sq, Skv, Hq) : 0; }
 
 int td_attention_fp8(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,

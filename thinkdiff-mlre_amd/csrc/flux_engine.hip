@@ -71,6 +71,10 @@ struct td_flux {
   bf16_t *mod_w, *mod_b, *proj_w, *proj_b;
   std::vector<DoubleW> dbl;
   std::vector<SingleW> sgl;
+  // Upper bounds of the attention scores of each block (bf16 attention: TdAttnParams::score_bound), from its QK-RMSNorm weights: the norm
+  // leaves |q'|, |k| <= sqrt(128) x max|w|, so q'.k <= premul x 128 x max|w_q| x max|w_k|.  Root context; refreshed lazily after weights change.
+  std::vector<float> dbl_bound, sgl_bound;
+  bool bounds_dirty = true;
   // workspace
   char* ws = nullptr;
   bf16_t *h, *xn, *qkv, *attn, *mlp, *cat, *ctx, *vout;
@@ -460,8 +464,49 @@ int td_flux_param_info(const td_flux* f, int idx, char* name_buf, int buf_len, i
   return TD_OK;
 }
 
+// Host copy of a 128-element norm weight -> max |w| (synchronous: called once per weight change, behind a device synchronise)
+static int norm_weight_max(const bf16_t* w, float* out) {
+  uint16_t h[128];
+  TD_CHECK_HIP(hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost));
+  float m = 0.f;
+  for (int i = 0; i < 128; ++i) {
+    const uint32_t u = (uint32_t)h[i] << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    v = fabsf(v);
+    if (!(v <= 3.0e38f)) v = 3.0e38f;      // NaN / inf weights: no bound
+    m = fmaxf(m, v);
+  }
+  *out = m;
+  return TD_OK;
+}
+// A bound is used only while it cannot push exp2(s - bound) out of fp32's normal range for ANY score in [-bound, bound]: 2 x bound < 110 octaves.
+static int refresh_score_bounds(td_flux* root) {
+  TD_CHECK_HIP(hipDeviceSynchronize());      // weight loads ran on the callers' streams
+  const float c = 0.08838834764831845f * 1.4426950408889634f * 128.0f * 1.02f;      // premul x head_dim, 2 % for the bf16 roundings of q' and k
+  constexpr float LIMIT = 48.0f;
+  root->dbl_bound.assign(root->dbl.size(), 0.f);
+  root->sgl_bound.assign(root->sgl.size(), 0.f);
+  for (size_t i = 0; i < root->dbl.size(); ++i) {
+    float a, b, cq, ck;
+    TD_TRY(norm_weight_max(root->dbl[i].norm_q, &a)); TD_TRY(norm_weight_max(root->dbl[i].norm_added_q, &cq));
+    TD_TRY(norm_weight_max(root->dbl[i].norm_k, &b)); TD_TRY(norm_weight_max(root->dbl[i].norm_added_k, &ck));
+    const float bound = c * fmaxf(a, cq) * fmaxf(b, ck);
+    root->dbl_bound[i] = bound > 0.f && bound <= LIMIT ? bound : 0.f;
+  }
+  for (size_t i = 0; i < root->sgl.size(); ++i) {
+    float a, b;
+    TD_TRY(norm_weight_max(root->sgl[i].norm_q, &a)); TD_TRY(norm_weight_max(root->sgl[i].norm_k, &b));
+    const float bound = c * a * b;
+    root->sgl_bound[i] = bound > 0.f && bound <= LIMIT ? bound : 0.f;
+  }
+  root->bounds_dirty = false;
+  return TD_OK;
+}
+
 int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t count, void* stream) {
   TD_CHECK_ARG(f && name && src, "td_flux_load_param: null argument");
+  (f->parent ? f->parent : f)->bounds_dirty = true;
   auto it = f->index.find(name);
   TD_CHECK_ARG(it != f->index.end(), "td_flux_load_param: unknown parameter '%s'", name);
   const Slot& s = f->slots[it->second];
@@ -592,6 +637,7 @@ int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float me
 
 int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream) {
   TD_CHECK_ARG(f, "td_flux_init_random: null handle");
+  (f->parent ? f->parent : f)->bounds_dirty = true;
   TD_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
   for (const Slot& s : f->slots)
     if (s.count == 128 && s.name.find(".norm_") != std::string::npos)
@@ -626,6 +672,10 @@ int td_flux_set_condition(td_flux* f, const void* prompt_embeds, int T, const vo
 int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, void* stream) {
   TD_CHECK_ARG(f && t_eff && n > 0 && n <= f->max_steps, "td_flux_set_timesteps: n=%d exceeds capacity %d", n, f ? f->max_steps : 0);
   TD_CHECK_ARG(f->cond_set, "td_flux_set_timesteps: call td_flux_set_condition first (temb includes the pooled text embedding)");
+  {
+    td_flux* root = f->parent ? f->parent : f;
+    if (root->bounds_dirty) TD_TRY(refresh_score_bounds(root));      // (once per weight change; set_timesteps calls are serial on the host)
+  }
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D;
   // The schedule scalars travel BY VALUE in a kernel argument (stream-ordered, no host buffer whose lifetime or reallocation
@@ -700,6 +750,8 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
   // 8-bit attention: its pack pass reads the raw projections and applies QK-norm + RoPE itself (bit-identical, one HBM round trip less)
   const bool rope_in_pack = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_FUSE") == nullptr;      // (the switch: A/B timing and the bit-identity test)
+  // bf16 attention: the block's score bound as the softmax's fixed reference point (no row maxima, no rescales); TD_ATTN_NO_BOUND: the running-maximum form (A/B)
+  const bool use_bound = root->attn_mode == TD_ATTENTION_BF16 && !root->bounds_dirty && getenv("TD_ATTN_NO_BOUND") == nullptr;
   const int q_int8 = root->precision == TD_PRECISION_INT8;
   // the LayerNorm ahead of an fp8 Linear writes e4m3 rows + scales, ahead of a bf16 one the bf16 rows
   // history scales (int8): this step quantises the MLP operands under the scales the previous step's maxima give
@@ -731,6 +783,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     }
     rp.wqA = w.norm_added_q; rp.wkA = w.norm_added_k; rp.wqB = w.norm_q; rp.wkB = w.norm_k;
     if (!rope_in_pack) TD_TRY(qk_rope(f, s, rp));
+    ap.score_bound = use_bound && (size_t)i < root->dbl_bound.size() ? root->dbl_bound[i] : 0.f;
     ap.O = f->attn; ap.ldo = D;
     // history scales: the attention epilogue writes its output as int8 under the previous step's per-token scale (the out-proj's A operand)
     const bool ao_hist = use_hist && (m8 & TD_FP8_OUT);
@@ -816,6 +869,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     }
     rp.wqA = rp.wqB = w.norm_q; rp.wkA = rp.wkB = w.norm_k;
     if (!rope_in_pack) TD_TRY(qk_rope(f, s, rp));
+    ap.score_bound = use_bound && (size_t)i < root->sgl_bound.size() ? root->sgl_bound[i] : 0.f;
     ap.O = f->cat; ap.ldo = D + M;
     if (sg_hist) { ap.q8 = f->aq; ap.ldq8 = D + M; ap.q8_inv = hiv; ap.q8_amax = ham; }   // the attention half of [attn | mlp] as int8, same per-token scale
     TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr));

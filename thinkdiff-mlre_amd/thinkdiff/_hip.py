@@ -121,6 +121,7 @@ def _declare(L):
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],
         "td_attention_bf16": [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, f32, i32, vp],
         "td_attention_fp8": [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, f32, vp, vp],
+        "td_attention_joint_prescaled_bf16": [vp, i64, vp, vp, i64, vp, i64, i32, i32, f32, vp],
         "td_attention_fp8_qk_rope": [vp, i64, i32, i32, i32, vp, i64, i32, i32, vp, vp, i32, vp, vp, vp, vp, f32, f32, vp, vp],
         "td_sample_top_p_bf16": [vp, i64, i32, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, vp, vp],
     }
@@ -196,6 +197,16 @@ def attention(q, k, v, out, Hq, Hkv, scale=None, causal=False):
     check(lib().td_attention_bf16(ptr(q), q.stride(1), q.stride(0), ptr(k), ptr(v), k.stride(1), k.stride(0),
                                   ptr(out), out.stride(1), out.stride(0), B, Sq, Skv, Hq, Hkv, 128,
                                   float(scale), int(causal), stream_ptr()))
+    return out
+
+
+def attention_joint_prescaled(q, k, v, out, H, score_bound=0.0):
+    """The FLUX engine's form of the joint attention: q [S, >= H*128] already multiplied by scale * log2(e); `score_bound` > 0 = a fixed
+    reference point of the softmax (td_attention_joint_prescaled_bf16)."""
+    for t in (q, k, v, out):
+        assert t.dim() == 2 and t.dtype == torch.bfloat16 and t.stride(1) == 1
+    assert k.stride() == v.stride() and q.shape[0] == k.shape[0]
+    check(lib().td_attention_joint_prescaled_bf16(ptr(q), q.stride(0), ptr(k), ptr(v), k.stride(0), ptr(out), out.stride(0), q.shape[0], H, float(score_bound), stream_ptr()))
     return out
 
 
