@@ -89,11 +89,11 @@ int td_attention_bf16(const void* q, int64_t ldq, int64_t q_bstride, const void*
 int td_attention_varlen_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo,
                              const int* seg_starts, int n_seg, int max_len, int Hq, int Hkv, float scale, void* stream);
 /* The joint attention in the form the FLUX engine calls it: q already carries scale x log2(e) (folded in where RoPE rounds q to bf16), so the
- * scores arrive in the exp2 domain; one batch entry, Hq == Hkv = H, head_dim 128.  score_bound > 0: an upper bound of every score q'.k the caller
- * vouches for, used as the FIXED reference point of the softmax -- no per-tile row maximum, no rescale.  FLUX has one by construction: the
- * QK-RMSNorm leaves |q'| <= premul x sqrt(128) x max|w_q| and |k| <= sqrt(128) x max|w_k|.  The bound need not be tight (a bf16 probability keeps
- * its mantissa at any magnitude, the sums are fp32) but 2 x bound must stay below ~110 octaves so that exp2(s - bound) cannot leave fp32's
- * normal range; a score above the bound is harmless.  0: the running-maximum form.  Replaces F.scaled_dot_product_attention inside
+ * scores arrive in the exp2 domain; one batch entry, Hq == Hkv = H, head_dim 128.  score_bound in (0, 48]: a bound of |q'.k| (log2 units) the
+ * caller vouches for -- the scores are then exponentiated as they are: no reference point, no per-tile row maximum, no rescale (a bf16 probability
+ * keeps its mantissa at any magnitude and the sums are fp32: exp2(+-48) is far inside the range).  FLUX has such a bound by construction: the
+ * QK-RMSNorm leaves |q'| <= premul x sqrt(128) x max|w_q| and |k| <= sqrt(128) x max|w_k|.  A score a few octaves past the bound is harmless.
+ * 0: the running-maximum form (any scores).  Replaces F.scaled_dot_product_attention inside
  * [ext] diffusers FluxAttnProcessor2_0 (after norm_q / norm_k and apply_rotary_emb). */
 int td_attention_joint_prescaled_bf16(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* o, int64_t ldo, int S, int H,
                                       float score_bound, void* stream);

@@ -142,10 +142,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
   float m_run = 0.f;                  // reference point of the row's exponentials (bf16-representable; set by the first tile)
   const bf16x8_t kone = {(short)(h5 == 0 ? 0x3F80 : 0), 0, 0, 0, 0, 0, 0, 0};   // K-side fragment of the reference k-step: column 0 = 1
   bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};                                       // Q-side: row 0 = -m_run
-  if constexpr (FIXED) {              // the caller's score bound is the reference point of every row, once and for all
-    m_run = bf16_ceil(p.score_bound);
-    qnegm[0] = h5 == 0 ? (short)f2bf(-m_run) : (short)0;
-  }
+
   const float c = p.scale * 1.4426950408889634f;
   const int q_pos = q0 + l31 + c_off;
 
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_lean_kernel(c
     if (t + 1 < nt) stage((t + 1) & 1, t + 1);
 
     f32x16_t st[2];
-    attn_tile_scores<PO>(st, qf, kone, qnegm, ka);      // S^T - m = K . Q^T - 1 . m
+    attn_tile_scores<PO, FIXED>(st, qf, kone, qnegm, ka);      // S^T - m = K . Q^T - 1 . m
 
     const int key0 = t * KV_TILE;
     if constexpr (BIAS) {   // additive score bias in the scaled domain: (s + bias/scale) * scale = s*scale + bias
@@ -360,10 +357,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
     for (int rr = 0; rr < 16; ++rr) lacc[rr] = 0.f;
     float m_run = 0.f;
     bf16x8_t qnegm = {0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (FIXED) {            // the caller's score bound is the reference point of every row and every part (the hand-off then merges with factors 1)
-      m_run = bf16_ceil(p.score_bound);
-      qnegm[0] = h5 == 0 ? (short)f2bf(-m_run) : (short)0;
-    }
     auto tile = [&](const int t, auto slot_tag) {
       constexpr unsigned SLOT = decltype(slot_tag)::value;
       constexpr unsigned PO = SLOT * TILE_BYTES;
@@ -372,7 +365,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_streamk_kerne
       if (t + 1 < ke) stage(SLOT ^ 1, t + 1);
 
       f32x16_t st[2];
-      attn_tile_scores<PO>(st, qf, kone, qnegm, ka);
+      attn_tile_scores<PO, FIXED>(st, qf, kone, qnegm, ka);
 
       const int key0 = t * KV_TILE;
       if (key0 + KV_TILE > Skv) {        // last tile: keys >= Skv are masked
@@ -552,7 +545,7 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   if (p.bias) TD_CHECK_ARG(p.Skv % 4 == 0 && ((uintptr_t)p.bias) % 16 == 0 && p.batch == 1, "td_attention: bias needs Skv %% 4 == 0, 16-byte alignment, batch 1");
   if (p.kv_lens) TD_CHECK_ARG(p.causal && !p.bias, "td_attention: per-sequence kv lengths exist for the causal kernel only");
   if (p.q_prescaled) TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts, "td_attention: pre-scaled q is a form of the joint (unmasked) attention only");
-  TD_CHECK_ARG(p.score_bound >= 0.f && p.score_bound < 1e30f && (p.score_bound == 0.f || p.q_prescaled), "td_attention: a score bound goes with pre-scaled q (joint attention), finite and >= 0");
+  TD_CHECK_ARG(p.score_bound >= 0.f && p.score_bound <= 48.f && (p.score_bound == 0.f || p.q_prescaled), "td_attention: a score bound goes with pre-scaled q (joint attention) and lies in (0, 48] octaves (0 = none)");
   if (p.q8) TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts && p.batch == 1 && p.q8_inv && p.q8_amax && p.ldq8 % 8 == 0 && ((uintptr_t)p.q8) % 8 == 0,
                          "td_attention: the int8 output form is for the joint attention of one batch entry, with 8-byte aligned rows");
   if (p.seg_starts) {   // packed segments: plain grid over (query tiles of the longest segment, heads, segments)
@@ -575,7 +568,11 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
       if (int rc = sk_pooled_workspace(dev, cus, stream, &ws)) return rc;
     }
     constexpr int lds_sk = lds + 16;        // + the ticket word
-    if (p.q_prescaled && p.score_bound > 0.f) {
+    if (p.q_prescaled && p.score_bound > 0.f && (p.variant & 0x400)) {      // A/B: row sums on the VALU (32 MFMAs per tile)
+      static std::atomic<unsigned long long> a12{0};
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true, true, false, true>, lds_sk, a12, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true, true, false, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
+    } else if (p.q_prescaled && p.score_bound > 0.f) {
       static std::atomic<unsigned long long> a10{0};
       if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true, true, true, true>, lds_sk, a10, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true, true, true, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
@@ -602,7 +599,11 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
     }
   } else {
-    if (p.q_prescaled && p.score_bound > 0.f) {
+    if (p.q_prescaled && p.score_bound > 0.f && (p.variant & 0x400)) {      // A/B: row sums on the VALU
+      static std::atomic<unsigned long long> a13{0};
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, false, true>, lds, a13, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, false, true>), grid, dim3(NW * 64), lds, stream, q);
+    } else if (p.q_prescaled && p.score_bound > 0.f) {
       static std::atomic<unsigned long long> a11{0};
       if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, true, true>, lds, a11, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, true, true>), grid, dim3(NW * 64), lds, stream, q);

@@ -76,7 +76,9 @@ __device__ __forceinline__ bf16x4_t attn_ds_read_tr16(const unsigned addr) {
 //    into a 16-register accumulator, every register the complete sum over the 64 keys) replaces 32 adds per tile and lane and
 //    the half swap at the end; the sum is over the bf16-rounded probabilities the P.V product consumes.
 // Per 64-key tile and wave: 38 MFMAs (was 32) against ~32 v_exp + 16 v_cvt_pk + 16 v_max3 (+ rare rescales).
-template <unsigned PO>
+// NOREF: no reference k-step (the FIXED form: the caller's score bound keeps exp2(s) itself inside the floating-point range, so the scores
+// are exponentiated as they are) -- 36 MFMAs per tile instead of 38.
+template <unsigned PO, bool NOREF = false>
 __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8_t (&qf)[8], const bf16x8_t kone, const bf16x8_t qnegm,
                                                  const unsigned (&ka)[8]) {
   // K fragments are fetched KPF MFMAs ahead of their use (pinned: hipcc would issue each read right before its consumer and
@@ -92,12 +94,12 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
   __builtin_amdgcn_sched_group_barrier(0x100, KPF, 0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    if ((e & 7) == 0) {      // the reference point first: st = 1 . (-m)
+    if (!NOREF && (e & 7) == 0) {      // the reference point first: st = 1 . (-m)
       st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qnegm, zero16, 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     if (e + KPF < 16) kf[e + KPF] = kread(e + KPF);
-    st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], st[e >> 3], 0, 0, 0);
+    st[e >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[e], qf[e & 7], (NOREF && (e & 7) == 0) ? zero16 : st[e >> 3], 0, 0, 0);
     if (e + KPF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
   }
@@ -107,9 +109,9 @@ __device__ __forceinline__ void attn_tile_scores(f32x16_t (&st)[2], const bf16x8
 // zero and m_run is 0: the reference point is set to the tile's row maximum whatever it is.
 // RS: row sums on the matrix pipe (lacc); otherwise they are added on the VALU into lacc[0] as HALF sums (the caller adds the
 // two lane halves at the end) -- the A/B of which pipe has room on a given shape.
-// FIXED: the reference point is a constant the caller knows to bound every score (TdAttnParams::score_bound; m_run and qnegm hold it from the
-// start): no row maximum, no branch, no rescale -- a bf16 probability keeps its 8 mantissa bits at any magnitude and the sums are fp32, so the
-// reference only has to keep exp2(s - ref) inside the floating-point range, not near 1.
+// FIXED: the caller knows a bound of every score (TdAttnParams::score_bound <= 48 octaves): the scores are exponentiated as they are -- no row
+// maximum, no branch, no rescale, no reference at all (m_run = 0).  A bf16 probability keeps its 8 mantissa bits at any magnitude and the sums
+// are fp32: exp2(s) <= 2^48, a row sum <= 2^61, and exp2(s) >= 2^-48 (|s| <= bound) -- all far inside the floating-point range.
 template <unsigned PO, bool PRE, bool RS = true, bool FIXED = false>
 __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t (&o)[4], f32x16_t& lacc, float& m_run, bf16x8_t& qnegm,
                                                      const bool first, const float c, const unsigned (&va)[2][4], const int h5) {

@@ -480,7 +480,7 @@ static int norm_weight_max(const bf16_t* w, float* out) {
   *out = m;
   return TD_OK;
 }
-// A bound is used only while it cannot push exp2(s - bound) out of fp32's normal range for ANY score in [-bound, bound]: 2 x bound < 110 octaves.
+// A bound is used only up to 48 octaves: the attention then exponentiates the scores as they are (|s| <= bound: exp2(s) and its sums stay far inside fp32).
 static int refresh_score_bounds(td_flux* root) {
   TD_CHECK_HIP(hipDeviceSynchronize());      // weight loads ran on the callers' streams
   const float c = 0.08838834764831845f * 1.4426950408889634f * 128.0f * 1.02f;      // premul x head_dim, 2 % for the bf16 roundings of q' and k

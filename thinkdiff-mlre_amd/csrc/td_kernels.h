@@ -81,9 +81,9 @@ struct TdAttnParams {
   // the exp2 domain and `scale` is not applied again; joint (non-causal, no bias / lengths / segments) attention only
   int q_prescaled = 0;
   // q_prescaled only: an upper bound of every score q'.k the caller can vouch for (FLUX: the QK-RMSNorm bounds |q'| and |k| by sqrt(128) x the
-  // largest norm weight, so q'.k <= premul x 128 x max|w_q| x max|w_k| -- a per-block constant).  > 0: the kernels use it as a FIXED reference
-  // point of the softmax (no per-tile row maximum, no rescale); it need not be tight (bf16 probabilities and fp32 sums do not care about
-  // magnitude within tens of octaves) and a score above it is harmless.  0: the running-maximum form.
+  // largest norm weight, so |q'.k| <= premul x 128 x max|w_q| x max|w_k| -- a per-block constant).  In (0, 48]: the kernels exponentiate the scores
+  // as they are -- no reference point, no per-tile row maximum, no rescale (bf16 probabilities and fp32 sums do not care about magnitude:
+  // exp2(+-48) and a sum of 2^13 of them are far inside the range); a score a few octaves above it is harmless.  0: the running-maximum form.
   float score_bound = 0.f;
   // int8 output instead of O (joint attention; the FLUX engine's history-scaled int8 mode): q8[b][row, head*128 + d] = clamp(rint(o * q8_inv[row]), +-127)
   // with the caller's per-row inverse scales, row maxima of |o| accumulated into q8_amax[row] (atomic max on float bits).  ldq8 in bytes.
