@@ -568,11 +568,7 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
       if (int rc = sk_pooled_workspace(dev, cus, stream, &ws)) return rc;
     }
     constexpr int lds_sk = lds + 16;        // + the ticket word
-    if (p.q_prescaled && p.score_bound > 0.f && (p.variant & 0x400)) {      // A/B: row sums on the VALU (32 MFMAs per tile)
-      static std::atomic<unsigned long long> a12{0};
-      if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true, true, false, true>, lds_sk, a12, dev)) return e;
-      hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true, true, false, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
-    } else if (p.q_prescaled && p.score_bound > 0.f) {
+    if (p.q_prescaled && p.score_bound > 0.f) {
       static std::atomic<unsigned long long> a10{0};
       if (int e = set_lds_attr_once(td_attn_fwd_d128_streamk_kernel<NW, true, true, true, true>, lds_sk, a10, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_streamk_kernel<NW, true, true, true, true>), dim3(cus), dim3(NW * 64), lds_sk, stream, q, ws, (int)grid.x, nt);
@@ -599,11 +595,7 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, true>), grid, dim3(NW * 64), lds, stream, q);
     }
   } else {
-    if (p.q_prescaled && p.score_bound > 0.f && (p.variant & 0x400)) {      // A/B: row sums on the VALU
-      static std::atomic<unsigned long long> a13{0};
-      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, false, true>, lds, a13, dev)) return e;
-      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, false, true>), grid, dim3(NW * 64), lds, stream, q);
-    } else if (p.q_prescaled && p.score_bound > 0.f) {
+    if (p.q_prescaled && p.score_bound > 0.f) {
       static std::atomic<unsigned long long> a11{0};
       if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, true, true>, lds, a11, dev)) return e;
       hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, false, true, true, true>), grid, dim3(NW * 64), lds, stream, q);
