@@ -573,7 +573,7 @@ def main():
             res["attention_tflops"] = at["flops"] / (at["ms"] * 1e-3) / 1e12 if at["ms"] > 0 else 0.0
             res["attention_roofline"] = {"bound": "mfma", "achieved": res["attention_tflops"], "peak": peak, "unit": "TFLOP/s",
                                          "frac": res["attention_tflops"] / peak,
-                                         "kernel": "td_attn_fwd_d128_streamk_kernel<8,true,true>" if a.attention == "bf16" else "td_attn_fp8_pack_kernel + td_attn_fwd_d128_fp8_kernel<8,true,true>",
+                                         "kernel": "td_attn_fwd_d128_streamk_kernel<8,true,true,true,true>" if a.attention == "bf16" else "td_attn_fp8_pack_kernel + td_attn_fwd_d128_fp8_kernel<8,true,true>",
                                          "launches": at["launches"], "avg_launch_us": at["ms"] * 1e3 / max(at["launches"], 1)}
         if world == 1 and a.precision == "bf16" and not a.no_fp8_leg:
             res["fp8"] = fp8_leg(pipe, G, rank)
