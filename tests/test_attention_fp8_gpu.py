@@ -256,6 +256,53 @@ def test_engine_fused_rope_is_bit_identical(hip, monkeypatch):
     assert torch.isfinite(fused.float()).all() and torch.equal(fused, two_pass)
 
 
+def test_engine_history_reference_points(hip, monkeypatch):
+    """From the second denoise step on, every row of the 8-bit attention starts from the reference point its largest score of the previous step gives
+    (TdAttnParams::ref_in / ref_out) instead of from its first tile's maximum.  References are integers, so a probability is rounded the same way
+    wherever its row's reference sits; what changes is where the tail is cut.  A 4-step denoise with the history against the same without it
+    (TD_ATTN8_NO_HREF) and against the oracle's switch."""
+    if _PROB["form"] != "linear":
+        pytest.skip("the engine runs the shipped (integer-conversion) form only")
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+    cfg = R.tiny_config(num_layers=2, num_single_layers=2)
+    sd = R.init_weights(cfg, seed=12)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=2, num_single_layers=2, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=512, max_txt_tokens=64, max_steps=8)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(13)
+    h2, w2, T, n = 20, 18, 45, 4                      # S = 405: 7 key tiles, ragged
+    lat = torch.randn(1, h2 * w2, 64, generator=g).bfloat16()
+    pe = torch.randn(1, T, cfg.joint_attention_dim, generator=g).bfloat16()
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g).bfloat16()
+    R.FP8_ATTENTION = True
+    try:
+        ref = R.denoise(sd, cfg, lat, pe, pool, h2, w2, n, guidance_scale=3.5)[0]
+    finally:
+        R.FP8_ATTENTION = False
+    sig = R.make_sigmas(n, h2 * w2)
+    m.set_condition(pe[0].cuda(), pool[0].cuda(), R.latent_image_ids(h2, w2))
+    m.set_timesteps([effective_scalar(float(s) * 1000.0, torch.bfloat16) for s in sig[:-1]], float((torch.tensor([3.5]).bfloat16() * 1000).float()))
+    m.set_attention("fp8")
+    outs = {}
+    for name in ("history", "plain", "history_again"):
+        if name == "plain":
+            monkeypatch.setenv("TD_ATTN8_NO_HREF", "1")
+        else:
+            monkeypatch.delenv("TD_ATTN8_NO_HREF", raising=False)
+        x = lat[0].cuda().contiguous()
+        m.denoise(x, sig)
+        torch.cuda.synchronize()
+        outs[name] = x.float().cpu()
+    monkeypatch.delenv("TD_ATTN8_NO_HREF", raising=False)
+    m.set_attention("bf16")
+    assert all(torch.isfinite(v).all() for v in outs.values())
+    e_h, e_p, d = _rel(outs["history"], ref), _rel(outs["plain"], ref), _rel(outs["history"], outs["plain"])
+    print(f"4-step tiny denoise, 8-bit attention: history~oracle {e_h:.4f}  plain~oracle {e_p:.4f}  history~plain {d:.4f}")
+    assert e_h < 2e-2 and e_p < 2e-2 and d < 1e-2
+    assert _rel(outs["history_again"], outs["history"]) < 2e-3      # (a fresh image starts without history: the first step is the plain path again)
+
+
 def test_engine_fp8_attention_matches_the_oracle_switch(hip):
     """td_flux_set_attention(TD_ATTENTION_FP8) on a tiny config (two double + two single blocks, one forward): the engine against
     oracle/flux_ref.py with FP8_ATTENTION -- as close as the bf16 engine is to the bf16 oracle -- and the distance between the two

@@ -356,6 +356,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) { lacc[rr] = 0.f; negm[rr] = LIN ? 56.f : 0.f; }
     float m_run = 0.f;      // the reference point, log2 units
+    // History reference (p.ref_in): the row starts where the previous denoise step's largest score put it.  `need_first`: a row without one
+    // (or no history at all) takes the first tile's maximum, as before; a row whose history turns out far too high for its first tile does too.
+    float smax_run = -INFINITY;      // the row's largest score so far, absolute log2 units (for p.ref_out)
+    bool need_first = true;
+    if (p.ref_in) {
+      const int href = p.ref_in[(size_t)head * p.Sq + min(q0 + l31, p.Sq - 1)];
+      need_first = __any(href < -(1 << 20));
+      if (!need_first) {
+        m_run = (float)href;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) negm[rr] = LIN ? 56.f - 8.f * m_run : -m_run;
+      }
+    }
 
     auto tile = [&](const int t, auto slot_tag) {
       constexpr int SLOT = decltype(slot_tag)::value;
@@ -396,12 +409,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
         }
       };
       i32x8_t pf;
-      const bool first = PROBE == 2 ? false : t == kb;
+      const bool first = PROBE == 2 ? false : (t == kb && need_first);
+      bool fix_low = false;      // (history) rows whose first tile sits in the subnormal bytes of their inherited reference start from the tile after all
       constexpr float LIMIT = LIN ? 8.f * REF_LIMIT + 56.f : REF_LIMIT;      // (LIN: 126, the byte of 448)
+      constexpr float LOW = LIN ? 8.f : -6.f;                                  // (LIN: the first normal byte, 2^-6)
       // the reference point moves: first tile of a part, or a probability about to leave e4m3's range (mx: the row maximum, reference-relative)
       auto move_reference = [&](const float mx) {
         const float xm = LIN ? (mx - 56.f) * 0.125f : mx;                                   // the row maximum in log2 units above the reference
-        float d = (first || mx > LIMIT) ? __builtin_ceilf(xm) - REF_HEADROOM : 0.f;      // the new reference relative to the old one (per row): an integer
+        float d = (first || mx > LIMIT || (fix_low && mx < LOW)) ? __builtin_ceilf(xm) - REF_HEADROOM : 0.f;      // the new reference relative to the old one (per row): an integer
         if (!(d > -INFINITY)) d = 0.f;
         if (!first) {
           const float alpha = __builtin_amdgcn_exp2f(-d);
@@ -453,7 +468,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
         mx = half_swap_max(mx);
       }
       if constexpr (PROBE == 2) mx = 0.f;
-      if (first || __any(mx > LIMIT)) move_reference(mx);
+      if (p.ref_out) smax_run = fmaxf(smax_run, LIN ? __builtin_fmaf(mx - 56.f, 0.125f, m_run) : mx + m_run);
+      // A row trusts its history even when its first tile is far below it (the peak comes later: that is what the history knows) -- unless the tile
+      // sits in the subnormal bytes (11+ octaves under where the row's maximum was last step): such a row starts from this tile like a row without
+      // history, so that a stale reference can never make a whole row underflow (some tile always contributes normal bytes).
+      if (t == kb && !need_first) fix_low = __any(mx < LOW);
+      if (first || fix_low || __any(mx > LIMIT)) move_reference(mx);
 
       // ---- P = exp2(.) as e4m3, in the byte order of the P.V product's B operand -------------------------------------------------
       if constexpr (LIN) {
@@ -504,6 +524,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       tile(t, S2{}); if (++t >= ke) break;
       tile(t, S3{}); if (++t >= ke) break;
     }
+    if (p.ref_out && h5 == 0 && q0 + l31 < p.Sq && smax_run > -INFINITY)      // this part's share of the row's largest score, as the next step's starting reference
+      __hip_atomic_fetch_max(p.ref_out + (size_t)head * p.Sq + q0 + l31, (int)__builtin_ceilf(smax_run) - (int)REF_HEADROOM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float l_run = lacc[0];
     // ---- hand-off of a split item: attention_bf16.hip's protocol, unchanged (state = O, reference, row sum) -----------------
     if (kb > 0 || ke < nt) {

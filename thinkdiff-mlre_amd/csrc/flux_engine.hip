@@ -91,6 +91,10 @@ struct td_flux {
   int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
   int attn_mode = 0;                        // parent: TD_ATTENTION_BF16 / TD_ATTENTION_FP8 (td_flux_set_attention)
   char* attn8_ws = nullptr;                 // packed e4m3 q | k | v^T of the 8-bit attention (per context)
+  // 8-bit attention, history reference points (TdAttnParams::ref_in / ref_out): per (block, head, token) where the softmax of the NEXT denoise step
+  // starts -- two buffers, read / written in turn (a launch reads one and max-accumulates into the other)
+  int* href[2] = {nullptr, nullptr};
+  int href_cur = 0, href_step = -1, href_T = 0, href_S = 0;      // href[href_cur] holds the references step `href_step` produced for this token layout
   std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
   // int8 with history scales (td_flux_set_act_scales): per (block tensor, token) the scale / inverse scale of THIS step, taken from the maxima the
@@ -229,13 +233,14 @@ int qk_rope(td_flux* f, hipStream_t s, const TdQkRopeParams& p) {
   return td_qk_norm_rope_launch(p, s);
 }
 // rope != null: the 8-bit attention's pack pass applies QK-RMSNorm + RoPE itself (the block loop skipped td_qk_norm_rope)
-int attn(td_flux* f, hipStream_t s, const TdAttnParams& p, const TdQkRopeParams* rope = nullptr) {
+int attn(td_flux* f, hipStream_t s, const TdAttnParams& p, const TdQkRopeParams* rope = nullptr, const int* ref_in = nullptr, int* ref_out = nullptr) {
   TraceScope ts(f, s, TD_TRACE_ATTN, 4.0 * p.Sq * (double)p.Skv * p.Hq * 128.0);
   const td_flux* root = f->parent ? f->parent : f;
   if (root->attn_mode == TD_ATTENTION_FP8) {      // both products on the e4m3 MFMA: pack pass + persistent kernel (csrc/attention_fp8.hip)
     TdAttnParams q = p;
     q.f8_ws = f->attn8_ws;
     q.variant = p.variant & 0x1000;
+    q.ref_in = ref_in; q.ref_out = ref_out;
     if (rope) {
       const TdQkRopeParams& r = *rope;
       q.rope_cos = r.cos; q.rope_sin = r.sin; q.rope_split = r.split; q.rope_eps = r.eps; q.rope_q_premul = r.q_premul;
@@ -287,11 +292,14 @@ int alloc_workspace(td_flux* f) {
       {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
       {(void**)&f->attn_ws, (int64_t)td_attn_streamk_ws_bytes()},
       {(void**)&f->attn8_ws, (int64_t)td_attn_fp8_ws_bytes((int)S, (int)S, cfg->num_heads)},
+      {(void**)&f->href[0], (int64_t)(cfg->num_layers + cfg->num_single_layers) * cfg->num_heads * S * 4},
+      {(void**)&f->href[1], (int64_t)(cfg->num_layers + cfg->num_single_layers) * cfg->num_heads * S * 4},
       {(void**)&f->hs_scale, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4}, {(void**)&f->hs_inv, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4},
       {(void**)&f->hs_amax, (int64_t)(2 * cfg->num_layers + cfg->num_single_layers) * S * 4},
   };
   f->hs_cap = (int)S;
   f->hs_step = -1;
+  f->href_step = -1;
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
   hipError_t e = hipMalloc((void**)&f->ws, (size_t)total);
@@ -750,6 +758,14 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
   // 8-bit attention: its pack pass reads the raw projections and applies QK-norm + RoPE itself (bit-identical, one HBM round trip less)
   const bool rope_in_pack = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_FUSE") == nullptr;      // (the switch: A/B timing and the bit-identity test)
+  // 8-bit attention: every row's softmax starts from the reference its largest score of the PREVIOUS step gives (and leaves this step's for the next);
+  // first steps, out-of-order steps and changed token layouts start from the first tile, as the stand-alone entry point does.  TD_ATTN8_NO_HREF: A/B.
+  const bool href_on = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_HREF") == nullptr;
+  const bool href_read = href_on && step > 0 && f->href_step == step - 1 && f->href_T == T && f->href_S == S;
+  const size_t href_blk = (size_t)H * S;
+  int* const href_out = href_on ? f->href[f->href_cur ^ 1] : nullptr;
+  const int* const href_in = href_read ? f->href[f->href_cur] : nullptr;
+  if (href_on) TD_CHECK_HIP(hipMemsetAsync(href_out, 0x80, (size_t)(L + Ls) * href_blk * 4, s));      // 0x80808080: far below any reference
   // bf16 attention: the block's score bound as the softmax's fixed reference point (no row maxima, no rescales); TD_ATTN_NO_BOUND: the running-maximum form (A/B)
   const bool use_bound = root->attn_mode == TD_ATTENTION_BF16 && !root->bounds_dirty && getenv("TD_ATTN_NO_BOUND") == nullptr;
   const int q_int8 = root->precision == TD_PRECISION_INT8;
@@ -790,7 +806,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     float* asc_o = f->hs_scale + (size_t)(L + Ls + i) * f->hs_cap;
     unsigned* aam_o = f->hs_amax + (size_t)(L + Ls + i) * f->hs_cap;
     if (ao_hist) { ap.q8 = f->aq; ap.ldq8 = D; ap.q8_inv = f->hs_inv + (size_t)(L + Ls + i) * f->hs_cap; ap.q8_amax = aam_o; }
-    TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr));
+    TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr, href_in ? href_in + (size_t)i * href_blk : nullptr, href_out ? href_out + (size_t)i * href_blk : nullptr));
     ap.q8 = nullptr;
     if (m8 & TD_FP8_OUT) {
       const DoubleW8& w8 = root->dbl8[i];
@@ -872,7 +888,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     ap.score_bound = use_bound && (size_t)i < root->sgl_bound.size() ? root->sgl_bound[i] : 0.f;
     ap.O = f->cat; ap.ldo = D + M;
     if (sg_hist) { ap.q8 = f->aq; ap.ldq8 = D + M; ap.q8_inv = hiv; ap.q8_amax = ham; }   // the attention half of [attn | mlp] as int8, same per-token scale
-    TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr));
+    TD_TRY(attn(f, s, ap, rope_in_pack ? &rp : nullptr, href_in ? href_in + (size_t)(L + i) * href_blk : nullptr, href_out ? href_out + (size_t)(L + i) * href_blk : nullptr));
     ap.q8 = nullptr;
     if (m8 & TD_FP8_SINGLE_OUT) {
       if (sg_hist) {
@@ -895,6 +911,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   TD_TRY(norm_rows(f, s, nf));
   TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
   if (hist_mode) { f->hs_step = step; f->hs_T = T; f->hs_S = S; } else f->hs_step = -1;
+  if (href_on) { f->href_cur ^= 1; f->href_step = step; f->href_T = T; f->href_S = S; } else f->href_step = -1;
   return TD_OK;
 }
 

@@ -90,6 +90,11 @@ struct TdAttnParams {
   uint8_t* q8 = nullptr; int ldq8 = 0; const float* q8_inv = nullptr; unsigned* q8_amax = nullptr;
   // td_attn_fp8_launch only: td_attn_fp8_ws_bytes(Sq, Skv, Hq) bytes of scratch for the packed e4m3 operands
   void* f8_ws = nullptr;
+  // td_attn_fp8_launch only: reference points carried from one denoise step to the next (ints, [Hq][Sq]).  ref_in (may be null): where each row's
+  // softmax starts -- ceil(the row's largest score of the PREVIOUS step) - headroom, in log2 units -- instead of the first tile's maximum, so that
+  // the reference hardly ever has to move (a move rescales O, the row sums and the scores: ~80 VALU instructions per wave); ref_out (may be null):
+  // receives the same quantity of THIS launch (atomic max: both owners of a split item contribute), to be preset to INT_MIN-like values by the caller.
+  const int* ref_in = nullptr; int* ref_out = nullptr;
   // td_attn_fp8_launch only (rope_cos != null): Q / K are the RAW projection outputs and the pack pass applies the per-head
   // QK-RMSNorm + interleaved-pair rotary embedding of td_qk_norm_rope_kernel on its way (same arithmetic, same summation order and
   // the same bf16 rounding points: bit-identical to the two-pass form), so that pass and its HBM round trip disappear.  Needs
