@@ -1,4 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/r3g_gpu_suite.log 2>&1 || { tail -40 gpurun_out/r3g_gpu_suite.log; exit 1; }
-tail -3 gpurun_out/r3g_gpu_suite.log
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/r3h_gpu_suite.log 2>&1 || { tail -40 gpurun_out/r3h_gpu_suite.log; exit 1; }
+tail -3 gpurun_out/r3h_gpu_suite.log
