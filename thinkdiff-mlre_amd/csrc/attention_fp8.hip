@@ -301,8 +301,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
     unsigned ksc_r[NSLOT], vsc_r[NSLOT];      // scale bytes of the tiles in the ring
     // Every iteration stages exactly one tile (indices past the end re-load the last one into a slot nobody reads): the number of
     // vector-memory operations in flight is then the same at every barrier, and the staging code has no branch -- it sits
-    // BETWEEN the P.V MFMAs (an LDS-DMA piece costs ~60 issue cycles, invisible under a 64-cycle MFMA, and ~600 per tile when all
-    // eight waves issue theirs together right after the barrier: rocprofv3 + ablations).
+    // inside the MFMA streams (an LDS-DMA piece costs ~60 issue cycles, invisible under a 64-cycle MFMA, and ~600 per tile when all
+    // eight waves issue theirs together right after the barrier: rocprofv3 + ablations), see stage_part below.
     auto stage = [&](auto slot_tag, int t_raw) {
       constexpr int SL = decltype(slot_tag)::value;
       const unsigned t = (unsigned)min(t_raw, nt - 1);
@@ -314,6 +314,21 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       }
       ksc_r[SL] = __builtin_amdgcn_raw_buffer_load_b16(rsKs, t * KV_TILE + l31 * 2, 0, 0);
       vsc_r[SL] = __builtin_amdgcn_raw_buffer_load_b8(rsVs, t, 0, 0);
+    };
+    // In the tile loop a stage goes out in two halves: the K piece (+ its scale bytes) behind the four score MFMAs, where the wave would only be waiting
+    // for their results, the V piece between the P.V MFMAs.  Measured in the denoise loop, alternated twice: whole stage between the P.V MFMAs 272.7 / 273.0 ms
+    // of attention per image, this split 267.0 / 266.2, whole stage behind the score MFMAs 270.3 / 269.5 (profiles/r3c_attention_fp8_stage_split_ab.log).
+    auto stage_part = [&](auto slot_tag, int t_raw, bool vpart) {
+      constexpr int SL = decltype(slot_tag)::value;
+      const unsigned t = (unsigned)min(t_raw, nt - 1);
+#pragma unroll
+      for (int pc = 0; pc < PIECES; ++pc) {
+        const unsigned piece = (unsigned)(wid * PIECES + pc) * 1024u;
+        if (!vpart) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (TD_LDS void*)(smem + SL * TILE8 + piece), 16, piece + (unsigned)lane * 16u + t * TILE8, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (TD_LDS void*)(smem + (NSLOT + SL) * TILE8 + piece), 16, piece + (unsigned)lane * 16u + t * TILE8, 0, 0, 0);
+      }
+      if (!vpart) ksc_r[SL] = __builtin_amdgcn_raw_buffer_load_b16(rsKs, t * KV_TILE + l31 * 2, 0, 0);
+      else vsc_r[SL] = __builtin_amdgcn_raw_buffer_load_b8(rsVs, t, 0, 0);
     };
     auto kread = [&](auto slot_tag, int kbk, int ks) {
       constexpr unsigned PO = decltype(slot_tag)::value * TILE8;
@@ -449,6 +464,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       st[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[3], qf[1], st[1], 0, 0, 1, ksc, 0, (int)qsc);
       vf[3] = vread(3);
       }
+      stage_part(FREE{}, t + 3, false);      // (behind the four score MFMAs in program order: the wave would only be waiting for them)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void td_attn_fwd_d128_fp8_kernel(co
       if constexpr (PROBE == 3) pf = qf[0];
       // ---- O^T += V8^T . P^T, row sums as one more row-block of ones; the next tile's K fragments under these MFMAs ---------
       lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf, lacc, 0, 0, 0, 127, 0, 127);
-      stage(FREE{}, t + 3);
+      stage_part(FREE{}, t + 3, true);
       if constexpr (PROBE != 5) o[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pf, o[0], 0, 0, 0, vsc, 0, 127);
       kf[0] = kread(NEXT{}, 0, 0);
       if constexpr (PROBE != 5) o[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pf, o[1], 0, 0, 0, vsc, 0, 127);
