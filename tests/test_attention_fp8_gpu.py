@@ -303,6 +303,40 @@ def test_engine_history_reference_points(hip, monkeypatch):
     assert _rel(outs["history_again"], outs["history"]) < 2e-3      # (a fresh image starts without history: the first step is the plain path again)
 
 
+def test_history_references_are_dropped_when_the_token_layout_changes(hip, monkeypatch):
+    """A forward at step 1 right after the conditioning changed (another text length): the references of the previous layout must not be read --
+    the result equals the plain path's bit for bit."""
+    if _PROB["form"] != "linear":
+        pytest.skip("the engine runs the shipped (integer-conversion) form only")
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=1, num_single_layers=1, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+    m.load_state_dict(R.init_weights(cfg, seed=14))
+    g = torch.Generator().manual_seed(15)
+    h2 = w2 = 12
+    lat = torch.randn(h2 * w2, 64, generator=g).bfloat16().cuda()
+    pool = torch.randn(cfg.pooled_projection_dim, generator=g).bfloat16().cuda()
+    sig = [1.0, 0.8, 0.5, 0.0]
+    m.set_attention("fp8")
+
+    def prepare(T):
+        m.set_condition(torch.randn(T, cfg.joint_attention_dim, generator=torch.Generator().manual_seed(T)).bfloat16().cuda(), pool, R.latent_image_ids(h2, w2))
+        m.set_timesteps([effective_scalar(s * 1000.0, torch.bfloat16) for s in sig[:-1]], 3500.0)
+
+    prepare(30)
+    m.forward_step(lat, 0)                                # leaves references for (T = 30, step 0)
+    prepare(41)                                           # another layout: S changes
+    a = m.forward_step(lat, 1).clone()                    # step 1 follows step 0, but on the old layout
+    monkeypatch.setenv("TD_ATTN8_NO_HREF", "1")
+    b = m.forward_step(lat, 1).clone()
+    monkeypatch.delenv("TD_ATTN8_NO_HREF")
+    m.set_attention("bf16")
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 def test_engine_fp8_attention_matches_the_oracle_switch(hip):
     """td_flux_set_attention(TD_ATTENTION_FP8) on a tiny config (two double + two single blocks, one forward): the engine against
     oracle/flux_ref.py with FP8_ATTENTION -- as close as the bf16 engine is to the bf16 oracle -- and the distance between the two

@@ -63,6 +63,39 @@ def test_transformer_forward_matches_oracle(hip, layers, singles, h2, w2, T):
     assert e_hip32 < 1.5 * e_ref + 2e-3
 
 
+@pytest.mark.parametrize("wscale", [1.0, 2.5, 0.05])
+def test_attention_score_bound_switch(hip, monkeypatch, wscale):
+    """The bf16 attention exponentiates the scores as they are while the block's QK-RMSNorm weights bound them by at most 48 octaves (norm weights
+    ~1: ~28 octaves), and falls back to the running-maximum form otherwise (norm weights x 2.5: ~180 octaves); tiny norm weights give a tiny bound.
+    Every case must match the oracle, and the bounded form must agree with the running-maximum form (TD_ATTN_NO_BOUND) on the same weights."""
+    cfg = R.tiny_config(num_layers=1, num_single_layers=1)
+    sd = R.init_weights(cfg, seed=21)
+    for k in list(sd):
+        if ".norm_" in k and k.endswith(".weight") and sd[k].dim() == 1:
+            sd[k] = (sd[k].float() * wscale).bfloat16()
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig
+    m = FluxTransformer2DModel(FluxTransformerConfig(
+        in_channels=cfg.in_channels, num_layers=1, num_single_layers=1, num_attention_heads=cfg.num_attention_heads,
+        joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim, guidance_embeds=cfg.guidance_embeds),
+        max_img_tokens=1024, max_txt_tokens=256, max_steps=8)
+    m.load_state_dict(sd)
+    h2, w2, T = 20, 24, 70                      # S = 550: more than one query tile, ragged key tail
+    lat, pe, pool = _inputs(cfg, h2, w2, T, seed=5)
+    img_ids, txt_ids = R.latent_image_ids(h2, w2), torch.zeros(T, 3)
+    t, g = torch.tensor([0.7324]), torch.tensor([3.5])
+    ref16 = R.transformer_forward(sd, cfg, lat, pe, pool, t.bfloat16(), img_ids.bfloat16(), txt_ids.bfloat16(), g)
+    out_b = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0].clone()
+    monkeypatch.setenv("TD_ATTN_NO_BOUND", "1")
+    out_r = m.forward(lat.cuda(), pe.cuda(), pool.cuda(), t.bfloat16().cuda(), img_ids, txt_ids, g)[0].clone()
+    monkeypatch.delenv("TD_ATTN_NO_BOUND")
+    torch.cuda.synchronize()
+    e_b, e_r, d = _rel_rmse(out_b, ref16), _rel_rmse(out_r, ref16), _rel_rmse(out_b, out_r)
+    print(f"norm weights x{wscale}: bounded-or-fallback~oracle {e_b:.4f}  running-max~oracle {e_r:.4f}  between them {d:.5f}")
+    assert torch.isfinite(out_b.float()).all() and e_b < 2e-2 and e_r < 2e-2 and d < 5e-3
+    if wscale == 2.5:
+        assert d == 0.0                         # bound > 48 octaves: the very same kernel ran both times
+
+
 def test_denoise_loop_matches_oracle(hip):
     """4 Euler steps, explicit latents (cfg-1 shape in miniature): final latents vs the oracle loop."""
     cfg = R.tiny_config(num_layers=2, num_single_layers=2)
