@@ -408,10 +408,15 @@ def denoise(sd, cfg: FluxConfig, latents_packed, prompt_embeds, pooled, h2, w2, 
     txt_ids = torch.zeros(prompt_embeds.shape[1], 3).to(dt).to(dev)
     guidance = torch.full([1], guidance_scale, dtype=torch.float32, device=dev).expand(B) if cfg.guidance_embeds else None
     x = latents_packed
+    sig_t = torch.from_numpy(sig).to(dev)                    # scheduler.sigmas: an fp32 tensor
     for i in range(num_steps):
         t = timesteps[i].expand(B).to(dt)
         v = transformer_forward(sd, cfg, x, prompt_embeds, pooled, t / 1000, img_ids, txt_ids, guidance)
-        x = (x.float() + float(sig[i + 1] - sig[i]) * v.float()).to(v.dtype)
+        # [ext] FlowMatchEulerDiscreteScheduler.step, statement for statement:
+        #   sample = sample.to(torch.float32); prev_sample = sample + (sigma_next - sigma) * model_output; prev_sample.to(model_output.dtype)
+        # `(sigma_next - sigma)` is a 0-dim fp32 tensor, so with a bf16 model_output the product is a bf16 op (torch promotes to the
+        # dimensioned operand's dtype: the scalar is cast to bf16 and the product rounded to bf16); the sum is fp32.
+        x = (x.to(torch.float32) + (sig_t[i + 1] - sig_t[i]) * v).to(v.dtype)
         if trace is not None:
             trace.append(x.clone())
     return x

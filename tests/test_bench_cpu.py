@@ -55,6 +55,32 @@ def test_a_failing_rank_fails_the_launcher():
     assert p.returncode != 0 and "rank 1 exited" in p.stderr and not p.stdout.strip()
 
 
+def test_eight_ranks_dry_run_and_per_rank_seconds():
+    """The driver's N = 8 case, rehearsed on the CPU (gloo): one line, every rank's own init / timed seconds in it."""
+    r = _line(_run("--gpus", "8", "--steps", "1", "--warmup", "0", "--dry-run"))
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak"
+    pr = r["per_rank_seconds"]
+    assert len(pr["timed_s"]) == 8 and len(pr["init_s"]) == 8 and all(v > 0 for v in pr["timed_s"])
+    assert abs(max(pr["timed_s"]) - r["ms_per_step"] / 1e3) < 1e-9 + 1e-6 * max(pr["timed_s"])       # `value` is computed from the MAX over ranks
+    r5 = _line(_run("--gpus", "8", "--dry-run", "--workload", "config5", "--prompts", "64", "--in-flight", "2"))
+    assert r5["n_gpus"] == 8 and r5["config"]["prompts"] == 64 and len(r5["per_rank_seconds"]["timed_s"]) == 8
+
+
+def test_world_size_comes_from_the_launcher_when_gpus_is_omitted():
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29743", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_hung_ranks_are_terminated_at_the_deadline():
+    p = _run("--gpus", "2", "--dry-run", "--timeout", "3", env={"TD_BENCH_HANG_RANK": "1"})
+    assert p.returncode == 124 and "still running" in p.stderr and not p.stdout.strip()
+
+
 def test_world_size_mismatch_is_an_error():
     p = _run("--gpus", "2", "--dry-run", env={"RANK": "0", "WORLD_SIZE": "1"})
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr

@@ -165,6 +165,41 @@ def test_linear_grouped_ragged_text_rows(hip, cfg):
     _close(d1, _ref_linear(x1, w1, b1, act=1), 2.0 ** -6)
 
 
+@pytest.mark.parametrize("split", ["auto", "2", "4"])
+@pytest.mark.parametrize("M0,M1,N,K", [(4096, 193, 12288, 256), (4096, 258, 9216, 128), (4354, 0, 21504, 128), (4096, 193, 4352, 512)])
+def test_linear_tail_split_is_bit_identical(hip, monkeypatch, M0, M1, N, K, split):
+    """Tile counts that leave a mostly empty last round of the 256 CUs (816 = 3.19 rounds, 612 = 2.39, 1 512 = 5.9 with ragged tiles, 289): the launcher
+    cuts the last tiles into 2 or 4 row sub-tiles (csrc/gemm_bf16.hip, TAIL).  Every output element is still one workgroup's full contraction, so the
+    result must equal the unsplit launch BIT FOR BIT -- with the grouped two-problem form, ragged last tiles, the gate / residual epilogue, int8 and e4m3."""
+    g = torch.Generator().manual_seed(M0 + N + K)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()
+    x0, w0, b0, g0, h0 = mk(M0, K).cuda(), (mk(N, K).float() * 0.05).bfloat16().cuda(), mk(N).cuda(), mk(N).cuda(), mk(M0, N).cuda()
+    two = M1 > 0
+    x1, w1, b1, g1, h1 = (mk(M1, K).cuda(), (mk(N, K).float() * 0.05).bfloat16().cuda(), mk(N).cuda(), mk(N).cuda(), mk(M1, N).cuda()) if two else (None,) * 5
+
+    def run():
+        d0, d1 = h0.clone(), (h1.clone() if two else None)
+        hip.linear_grouped2(x0, w0, b0, d0, x1, w1, b1, d1, gate0=g0, res0=d0, gate1=g1 if two else None, res1=d1, tile_cfg=0)
+        xq, xs = hip.quant_rows_int8(x0)
+        wq, ws = hip.quant_rows_int8(w0)
+        y8 = hip.linear_int8(xq, xs, wq, ws, b0, act=hip.ACT_GELU_TANH, tile_cfg=0)
+        xf, xfs = hip.quant_rows_fp8(x0)
+        wf, wfs = hip.quant_rows_fp8(w0)
+        yf = hip.linear_fp8(xf, xfs, wf, wfs, b0, tile_cfg=0)
+        torch.cuda.synchronize()
+        return d0, d1, y8, yf
+    monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
+    base = run()
+    monkeypatch.delenv("TD_GEMM_NO_TAIL")
+    if split != "auto":
+        monkeypatch.setenv("TD_GEMM_TAIL", split)
+    got = run()
+    for a, b in zip(got, base):
+        if a is not None:
+            assert torch.equal(a, b)
+    _close(got[0], _ref_linear(x0.cpu(), w0.cpu(), b0.cpu(), gate=g0.cpu(), res=h0.cpu()))
+
+
 @pytest.mark.parametrize("M,N,K", [(4289, 3072, 1024), (449, 9216, 512), (100, 192, 64), (289, 200, 128)])
 def test_linear_tile_288x192(hip, M, N, K):
     g = torch.Generator().manual_seed(M + N)

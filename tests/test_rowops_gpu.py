@@ -82,11 +82,19 @@ def test_euler_pack_unpack_pool_bit_exact(hip):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(4096, 64, generator=g).bfloat16()
     v = torch.randn(4096, 64, generator=g).bfloat16()
-    dt = -0.0116
-    ref = (x.float() + dt * v.float()).bfloat16()
-    out = hip.euler_step(x.cuda().clone(), v.cuda(), dt)
-    torch.cuda.synchronize()
-    assert torch.equal(out.cpu(), ref)            # product and sum round separately, as torch's mul + add do
+    # the scheduler's own statement, tensor form ([ext] diffusers 0.31.0 FlowMatchEulerDiscreteScheduler.step): sigmas is an fp32 tensor,
+    # model_output a bf16 tensor, so `(sigma_next - sigma) * model_output` is a bf16 op (scalar cast to bf16, product rounded to bf16)
+    for s0, s1 in ((0.9731, 0.9615), (1.0, 0.98828), (0.0357, 0.0)):
+        sig = torch.tensor([s0, s1], dtype=torch.float32)
+        prod = (sig[1] - sig[0]) * v
+        assert prod.dtype == torch.bfloat16
+        ref = (x.to(torch.float32) + prod).to(v.dtype)
+        out = hip.euler_step(x.cuda().clone(), v.cuda(), float(sig[1] - sig[0]))
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref)
+        # torch on the GPU (where the reference runs configs 2-5) applies the same promotion to a 0-dim device tensor
+        ref_gpu = (x.cuda().to(torch.float32) + (sig.cuda()[1] - sig.cuda()[0]) * v.cuda()).to(v.dtype)
+        assert torch.equal(ref_gpu.cpu(), ref)
     lat = torch.randn(16, 32, 48, generator=g).bfloat16()
     p = hip.flux_pack_latents(lat.cuda())
     assert torch.equal(p.cpu(), R.pack_latents(lat[None])[0])

@@ -30,7 +30,9 @@ def test_ops_match_the_c_abi_binding(hip):
     p = O.flux_pack_latents(lat)
     assert torch.equal(O.flux_unpack_latents(p, 16, 32, 48, 1.0, 0.0), lat)
     xv, vv = torch.randn(4096, generator=g).bfloat16().cuda(), torch.randn(4096, generator=g).bfloat16().cuda()
-    want = (xv.float() + (-0.0116) * vv.float()).bfloat16()
+    # scheduler.step's product: a 0-dim fp32 tensor ON THE DEVICE (scheduler.sigmas lives there) x a bf16 tensor = a bf16 op, scalar cast to bf16
+    # (a 0-dim CPU tensor would instead enter the kernel as an fp32 scalar -- not what the pipeline does)
+    want = (xv.float() + torch.tensor(-0.0116, device="cuda") * vv).bfloat16()
     assert O.euler_step_(xv, vv, -0.0116) is xv and torch.equal(xv, want)
     ids = O.sample_top_p(torch.randn(4, 4096, generator=g).bfloat16().cuda(), 0.0, 0.9, 1, 0)
     assert ids.dtype == torch.int32 and ids.shape == (4,)

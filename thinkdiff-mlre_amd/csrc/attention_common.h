@@ -117,9 +117,12 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16_t (&st)[2], f32x16_t
                                                      const bool first, const float c, const unsigned (&va)[2][4], const int h5) {
   const float cc = PRE ? 1.0f : c;
   if constexpr (!FIXED) {
-  float mx = st[0][0];
+  // The FIRST read of the fresh QK^T accumulators is one the compiler can see (fmaxf): its hazard recogniser then places the wait states a
+  // VALU read of a 16-pass MFMA result needs.  Inline-asm v_max3 alone is invisible to it and may read registers the matrix pipe has
+  // not written yet (csrc/attention_fp8.hip met exactly that: a row maximum that missed elements, about one row in 600).
+  float mx = fmaxf(st[0][15], st[1][15]);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) mx = max3(mx, st[0][r], st[1][r]);
+  for (int r = 0; r < 15; ++r) mx = max3(mx, st[0][r], st[1][r]);
   mx = half_swap_max(mx);
   constexpr float RESCALE_LOG2 = 8.0f;        // deferred rescale: probabilities may reach 2^8 before the reference moves
   if (first || __any(mx * cc > RESCALE_LOG2)) {

@@ -298,15 +298,20 @@ int td_temb_combine_silu_launch(const bf16_t* te, const bf16_t* ge, const bf16_t
   return 0;
 }
 
-// FlowMatchEulerDiscreteScheduler.step: x = bf16(float(x) + dt * float(v))   [ext scheduling_flow_match_euler_discrete.py]
+// FlowMatchEulerDiscreteScheduler.step [ext scheduling_flow_match_euler_discrete.py]:
+//   prev_sample = sample.float() + (sigma_next - sigma) * model_output;  prev_sample.to(model_output.dtype)
+// `(sigma_next - sigma)` is a 0-dim fp32 tensor and `model_output` a bf16 tensor, so torch's type promotion makes the PRODUCT a bf16
+// op: the scalar is cast to bf16, the product is rounded to bf16, and only the sum with the fp32 sample is fp32.  Three roundings:
+//   x = bf16(float(x) + float(bf16(float(bf16(dt)) * float(v))))
 __global__ void td_euler_step_kernel(bf16_t* x, const bf16_t* v, float dt, int n8) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n8) return;
   float a[8], b[8];
   unpack8(((const u32x4_t*)x)[idx], a);
   unpack8(((const u32x4_t*)v)[idx], b);
+  const float dtb = rbf(dt);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = mul_then_add(a[i], dt, b[i]);   // torch: sample + dt * model_output, two fp32 roundings (no fma)
+  for (int i = 0; i < 8; ++i) a[i] = a[i] + rbf(dtb * b[i]);   // rbf() between the product and the sum: nothing to contract into an fma
   ((u32x4_t*)x)[idx] = pack8(a);
 }
 
@@ -734,12 +739,15 @@ int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, floa
 }
 
 // ---- int8 with scales fixed in advance (the engine's history-scaled mode) ----------------------------------------------------------------
-// amax bits -> this step's scale = max(amax, tiny) * margin / 127 and its inverse; the accumulators are cleared for the step being started
+// amax bits -> this step's scale = amax * margin / 127 and its inverse; the accumulators are cleared for the step being started.
+// amax == 0 is "no history for this row" (the engine invalidates history whenever the tensor may not have been produced in 8-bit form last
+// step, so what is left is a row that really was all zeros): such a row takes the unit step, not a vanishing one that would saturate
+// every byte of the next non-zero value.
 __global__ void td_q8_scales_from_amax_kernel(unsigned* amax, float* scale, float* inv, long long n, float margin) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float a = fmaxf(as_f32(amax[i]), 1e-30f);
-  const float s = a * margin * (1.0f / 127.0f);
+  const float a = as_f32(amax[i]);
+  const float s = a > 0.f ? a * margin * (1.0f / 127.0f) : 1.0f;
   scale[i] = s;
   inv[i] = 1.0f / s;
   amax[i] = 0u;

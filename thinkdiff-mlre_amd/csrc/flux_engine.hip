@@ -95,6 +95,11 @@ struct td_flux {
   // starts -- two buffers, read / written in turn (a launch reads one and max-accumulates into the other)
   int* href[2] = {nullptr, nullptr};
   int href_cur = 0, href_step = -1, href_T = 0, href_S = 0;      // href[href_cur] holds the references step `href_step` produced for this token layout
+  // History (href, hs_*) is the previous step's state OF THE SAME IMAGE UNDER THE SAME NUMERIC CONFIGURATION: set_condition / set_timesteps forget it on
+  // their context; every setter that changes weights, precision, Linear classes, scale mode or attention mode bumps the parent's `hist_epoch`, and a
+  // context trusts its history only when it was recorded in the current epoch.
+  int hist_epoch = 0;                       // parent
+  int href_epoch = -1, hs_epoch = -1;       // per context: the epoch href / hs_amax were recorded in
   std::vector<float> tv_host;               // host staging of the schedule scalars (td_flux_set_timesteps)
   float *xs = nullptr, *as_ = nullptr;
   // int8 with history scales (td_flux_set_act_scales): per (block tensor, token) the scale / inverse scale of THIS step, taken from the maxima the
@@ -515,6 +520,7 @@ static int refresh_score_bounds(td_flux* root) {
 int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t count, void* stream) {
   TD_CHECK_ARG(f && name && src, "td_flux_load_param: null argument");
   (f->parent ? f->parent : f)->bounds_dirty = true;
+  ++(f->parent ? f->parent : f)->hist_epoch;
   auto it = f->index.find(name);
   TD_CHECK_ARG(it != f->index.end(), "td_flux_load_param: unknown parameter '%s'", name);
   const Slot& s = f->slots[it->second];
@@ -530,6 +536,7 @@ int td_flux_set_fp8_gemms(td_flux* f, unsigned mask) {
   TD_CHECK_ARG(f && !f->parent, "td_flux_set_fp8_gemms: set it on the parent context (forks follow it)");
   TD_CHECK_ARG((mask & ~(unsigned)TD_FP8_ALL_GEMMS) == 0, "td_flux_set_fp8_gemms: unknown bits in mask 0x%x", mask);
   f->fp8_mask = mask;
+  ++f->hist_epoch;
   return TD_OK;
 }
 
@@ -540,6 +547,7 @@ int td_flux_set_fp8_gemms(td_flux* f, unsigned mask) {
 int td_flux_set_act_scales(td_flux* f, int mode) {
   TD_CHECK_ARG(f && !f->parent && (mode == 0 || mode == 1), "td_flux_set_act_scales: parent context, mode 0 or 1");
   f->act_scale_mode = mode;
+  ++f->hist_epoch;
   return TD_OK;
 }
 
@@ -549,12 +557,14 @@ int td_flux_set_act_scales(td_flux* f, int mode) {
 int td_flux_set_attention(td_flux* f, int mode) {
   TD_CHECK_ARG(f && !f->parent && (mode == TD_ATTENTION_BF16 || mode == TD_ATTENTION_FP8), "td_flux_set_attention: parent context, TD_ATTENTION_BF16 or TD_ATTENTION_FP8");
   f->attn_mode = mode;
+  ++f->hist_epoch;
   return TD_OK;
 }
 
 int td_flux_set_precision(td_flux* f, int precision, void* stream) {
   TD_CHECK_ARG(f && (precision == TD_PRECISION_BF16 || precision == TD_PRECISION_FP8_E4M3 || precision == TD_PRECISION_INT8), "td_flux_set_precision: unknown precision %d", precision);
   TD_CHECK_ARG(!f->parent, "td_flux_set_precision: set the precision on the parent context (forks follow it)");
+  ++f->hist_epoch;
   if (precision == TD_PRECISION_BF16) { f->precision = precision; return TD_OK; }
   TD_CHECK_ARG(f->D % 128 == 0 && f->M % 128 == 0, "td_flux_set_precision: fp8 needs inner widths that are multiples of 128");
   hipStream_t s = (hipStream_t)stream;
@@ -646,6 +656,7 @@ int td_fill_normal_bf16(void* dst, int64_t n, uint64_t seed, float std, float me
 int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream) {
   TD_CHECK_ARG(f, "td_flux_init_random: null handle");
   (f->parent ? f->parent : f)->bounds_dirty = true;
+  ++(f->parent ? f->parent : f)->hist_epoch;
   TD_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
   for (const Slot& s : f->slots)
     if (s.count == 128 && s.name.find(".norm_") != std::string::npos)
@@ -672,6 +683,7 @@ int td_flux_set_condition(td_flux* f, const void* prompt_embeds, int T, const vo
   TD_TRY(td_flux_rope_table_launch(f->ids, T + S_img, f->cfg.axes_dims, (double)f->cfg.rope_theta, f->cosT, f->sinT, s));
   f->cond_set = true;
   f->n_steps = 0;
+  f->hs_step = f->href_step = -1;      // another image: the previous one's maxima / reference points say nothing about it
   return TD_OK;
 }
 
@@ -711,6 +723,7 @@ int td_flux_set_timesteps(td_flux* f, const float* t_eff, int n, float g_eff, vo
   TD_TRY(td_temb_combine_silu_launch(f->te, f->cfg.guidance_embeds ? f->ge : nullptr, f->pe, n, D, f->temb, f->st, s));
   TD_TRY(gemm_big_n(f, s, f->st, D, f->mod_w, f->mod_b, f->mods, f->NMOD, n, f->NMOD, D));
   f->n_steps = n;
+  f->hs_step = f->href_step = -1;      // another schedule: "the previous step" of the old one is not this one's
   return TD_OK;
 }
 
@@ -761,7 +774,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   // 8-bit attention: every row's softmax starts from the reference its largest score of the PREVIOUS step gives (and leaves this step's for the next);
   // first steps, out-of-order steps and changed token layouts start from the first tile, as the stand-alone entry point does.  TD_ATTN8_NO_HREF: A/B.
   const bool href_on = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_HREF") == nullptr;
-  const bool href_read = href_on && step > 0 && f->href_step == step - 1 && f->href_T == T && f->href_S == S;
+  const bool href_read = href_on && step > 0 && f->href_step == step - 1 && f->href_T == T && f->href_S == S && f->href_epoch == root->hist_epoch;
   const size_t href_blk = (size_t)H * S;
   int* const href_out = href_on ? f->href[f->href_cur ^ 1] : nullptr;
   const int* const href_in = href_read ? f->href[f->href_cur] : nullptr;
@@ -773,7 +786,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   // history scales (int8): this step quantises the MLP operands under the scales the previous step's maxima give
   const int nT = 2 * L + Ls;
   const bool hist_mode = q_int8 && root->act_scale_mode == 1;
-  const bool use_hist = hist_mode && step > 0 && f->hs_step == step - 1 && f->hs_T == T && f->hs_S == S;
+  const bool use_hist = hist_mode && step > 0 && f->hs_step == step - 1 && f->hs_T == T && f->hs_S == S && f->hs_epoch == root->hist_epoch;
   if (hist_mode) {
     if (use_hist) TD_TRY(td_q8_scales_from_amax_launch(f->hs_amax, f->hs_scale, f->hs_inv, (long long)nT * f->hs_cap, 1.25f, s));
     else TD_CHECK_HIP(hipMemsetAsync(f->hs_amax, 0, (size_t)nT * f->hs_cap * 4, s));
@@ -910,8 +923,8 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
   TD_TRY(norm_rows(f, s, nf));
   TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
-  if (hist_mode) { f->hs_step = step; f->hs_T = T; f->hs_S = S; } else f->hs_step = -1;
-  if (href_on) { f->href_cur ^= 1; f->href_step = step; f->href_T = T; f->href_S = S; } else f->href_step = -1;
+  if (hist_mode) { f->hs_step = step; f->hs_T = T; f->hs_S = S; f->hs_epoch = root->hist_epoch; } else f->hs_step = -1;
+  if (href_on) { f->href_cur ^= 1; f->href_step = step; f->href_T = T; f->href_S = S; f->href_epoch = root->hist_epoch; } else f->href_step = -1;
   return TD_OK;
 }
 

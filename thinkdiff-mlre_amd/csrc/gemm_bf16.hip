@@ -253,9 +253,9 @@ __device__ __forceinline__ void epilogue_f32(const TdGemmParams& pp, const ProbV
 // swizzle, W ring, instruction interleave -- with the other MFMA and k-tiles of 128 elements; the int32 accumulators are exact and
 // become floats (x a_scale[m] x w_scale[n]) in front of the common epilogue.  Round 3: 8-bit operands whose quantisation noise is
 // ~4x below e4m3's on Gaussian-like operands (uniform step max/127 against a 3-bit mantissa).
-template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false>
-__global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
+// One output tile: rows [m0, m0 + 32 WM) of problem `second_prob`, columns [n0, n0 + 64 WN).  Called once per workgroup.
+template <int WM, int WN, bool CONV, bool FP8, bool I8>
+__device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, const bool second_prob, const int m0, const int n0) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
   constexpr int GA = BM / 8, GW = BN / 8;           // 8-row staging groups per tile
@@ -265,31 +265,11 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   static_assert(!(FP8 || I8) || !CONV, "no 8-bit convolution");
   static_assert(!(FP8 && I8), "one operand type");
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
-  // ---- XCD-aware tile mapping -------------------------------------------------------------
-  int tm, tn;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int gid = t / per_group;
-    const int first_m = gid * GROUP_M;
-    const int gsize = min(p.tiles_m - first_m, GROUP_M);
-    const int in_g = t - gid * per_group;
-    tm = first_m + in_g % gsize;
-    tn = in_g / gsize;
-  }
-  // grouped launch: m-tiles [0, tiles_m0) belong to problem 0, the rest to problem 1 (same N, K, strides)
-  const bool second_prob = tm >= p.tiles_m0;
-  if (second_prob) tm -= p.tiles_m0;
   const bf16_t* Aptr = second_prob ? p.g_A : p.A;
   const bf16_t* Wptr = second_prob ? p.g_W : p.W;
   ProbView pv;
@@ -299,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   pv.C = second_prob ? p.g_C : p.C;
   pv.M = second_prob ? p.g_M : p.M;
   pv.q8 = second_prob ? p.g_q8 : p.q8; pv.q8_inv = second_prob ? p.g_q8_inv : p.q8_inv; pv.q8_amax = second_prob ? p.g_q8_amax : p.q8_amax;
-  const int m0 = tm * BM, n0 = tn * BN;
+  if (m0 >= pv.M) return;      // (a sub-tile of a split tail tile that lies wholly below the problem's last row; workgroup-uniform)
 
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
   const unsigned bytesA = CONV ? (unsigned)((long long)(p.conv_H >> p.conv_up) * (p.conv_W >> p.conv_up) * p.conv_Cin * 2)
@@ -629,12 +609,93 @@ __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmPar
   }
   const int mode = act != TD_ACT_NONE ? 0 : (pv.gate ? 1 : (pv.res ? 2 : 0));
   epilogue<WM, WN, I8 && WN == 4>(p, pv, acc, mbeg, nbeg, second, act, mode);
+}
+
+// XCD-aware numbering: workgroup ids go round-robin over the 8 XCDs; logical index t gives every XCD one CONTIGUOUS run of tiles (its 32 resident
+// tiles then share A / W panels through that XCD's L2), in dispatch order inside the run.
+__device__ __forceinline__ int xcd_contiguous(const int bid, const int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+
+// TAIL > 1 (256-row tiles, no conv): the launcher found that the tile count leaves a last, mostly empty round of the chip's CUs
+// (816 tiles on 256 CUs = 3.19 rounds: the launch takes 4 tile times), and cut the LAST `tail_tiles` tiles -- the ones dispatched
+// behind the full rounds -- into TAIL sub-tiles of 32 WM / TAIL rows each: workgroups [tail_first_wg, grid) take one sub-tile, so the
+// last round costs 1 / TAIL of a tile time (x the smaller tile's lower efficiency) instead of a whole one.  No split along K, no
+// fix-up pass: every output element is still produced by one workgroup with the full contraction, bit-identical to the unsplit launch.
+template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false, int TAIL = 1>
+__global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
+  static_assert(TAIL == 1 || (WM % TAIL == 0 && !CONV), "tail sub-tiles cut the m extent of the tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 32 * WM, BN = 64 * WN;
+  int t, sub = 0;
+  bool tail = false;
+  if (TAIL > 1 && (int)blockIdx.x >= p.tail_first_wg) {
+    const int u = xcd_contiguous((int)blockIdx.x - p.tail_first_wg, (int)gridDim.x - p.tail_first_wg);
+    t = p.tail_first_wg + u / TAIL;      // (full tiles: one workgroup each, so the first tail tile's logical index is tail_first_wg)
+    sub = u - (u / TAIL) * TAIL;
+    tail = true;
+  } else {
+    t = xcd_contiguous((int)blockIdx.x, TAIL > 1 ? p.tail_first_wg : (int)gridDim.x);
+  }
+  // grouped M ordering of the logical index
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int gid = t / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = t - gid * per_group;
+  int tm = first_m + in_g % gsize;
+  const int tn = in_g / gsize;
+  // grouped launch: m-tiles [0, tiles_m0) belong to problem 0, the rest to problem 1 (same N, K, strides)
+  const bool second_prob = tm >= p.tiles_m0;
+  if (second_prob) tm -= p.tiles_m0;
+  if constexpr (TAIL > 1) {
+    if (tail) {
+      gemm_tile<WM / TAIL, WN, CONV, FP8, I8>(p, smem, second_prob, tm * BM + sub * (BM / TAIL), tn * BN);
+      return;
+    }
+  }
+  gemm_tile<WM, WN, CONV, FP8, I8>(p, smem, second_prob, tm * BM, tn * BN);
 #endif
 }
 
 namespace {
 
-template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false>
+// How many CUs the device has (the round size of a one-workgroup-per-CU grid); cached per device.
+int cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cached[dev & 63].load(std::memory_order_acquire);
+  if (v <= 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_release);
+  }
+  return v;
+}
+
+// Tail split of a grid of `tiles` equal tiles on `cus` CUs (one workgroup per CU): the launch takes ceil(tiles / cus) tile times.  Cutting the
+// last `rem = tiles mod cus` tiles into s sub-tiles makes it floor(tiles / cus) + ceil(rem s / cus) / s x (what the smaller tile loses in
+// efficiency: measured ~8 % at s = 2, ~15 % at s = 4).  Returns the best s in {1, 2, 4} -- 1 unless a split saves at least 4 % of the launch.
+int tail_split(long long tiles, int cus) {
+  if (getenv("TD_GEMM_NO_TAIL")) return 1;      // (A/B switch; read per launch so one process can time both)
+  if (const char* f = getenv("TD_GEMM_TAIL")) return atoi(f) == 2 || atoi(f) == 4 ? atoi(f) : 1;
+  const long long full = tiles / cus, rem = tiles % cus;
+  if (rem == 0 || full == 0) return 1;          // (less than one round: the tile chooser already picks a smaller tile there)
+  const double base = (double)(full + 1);
+  double best = base * 0.96;
+  int pick = 1;
+  for (int s2 = 2; s2 <= 4; s2 *= 2) {
+    const double cost = (double)full + (double)((rem * s2 + cus - 1) / cus) / s2 * (s2 == 2 ? 1.08 : 1.15);
+    if (cost < best) { best = cost; pick = s2; }
+  }
+  return pick;
+}
+
+template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false, int TAIL = 1>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int LDS = (2 * BM + 3 * BN) * ROW_BYTES;
@@ -644,17 +705,27 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   p.ragged_rows = getenv("TD_GEMM_NO_RAGGED") ? 0 : 64;      // (A/B switch of the ragged-tile loop; read per launch so one process can time both)
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
+  int grid = p.tiles_m * p.tiles_n;
+  if constexpr (TAIL == 1 && WM == 8 && WN == 4 && !CONV) {      // the 256 x 256 tile of the block Linears: see whether its last round is worth cutting up
+    const int s = tail_split(grid, cu_count());
+    if (s == 2) return launch_cfg<WM, WN, CONV, FP8, I8, 2>(p0, stream);
+    if (s == 4) return launch_cfg<WM, WN, CONV, FP8, I8, 4>(p0, stream);
+  }
+  if constexpr (TAIL > 1) {
+    const int cus = cu_count();
+    p.tail_first_wg = grid / cus * cus;                        // a multiple of 8: the XCD numbering of both parts stays aligned
+    grid = p.tail_first_wg + (grid - p.tail_first_wg) * TAIL;
+  }
   // the dynamic-LDS limit is a per-device function attribute: set it once per device (a process may drive several)
   static std::atomic<unsigned long long> attr_done{0ull};
   int dev = 0;
   TD_CHECK_HIP(hipGetDevice(&dev));
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8>,
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
-  const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }

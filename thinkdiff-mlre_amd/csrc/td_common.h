@@ -39,14 +39,6 @@ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// a + b * c with the product rounded to fp32 before the sum: what two separate torch ops (mul, then add) compute.
-// hipcc contracts a plain `a + b * c` (and __fadd_rn(a, __fmul_rn(b, c))) into one fma, which rounds once.
-__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
-#pragma clang fp contract(off)
-  const float p = b * c;
-  return a + p;
-}
-
 // ---- activations (fp32 math) -------------------------------------------
 // Written on v_exp_f32 / v_rcp_f32 directly: a plain `/` compiles to the ~12-instruction IEEE division sequence, which made the
 // GELU epilogue of a 256x256 GEMM tile cost ~16 % of the tile (128 values per lane).  rcp / exp2 are good to 1 ulp, far inside

@@ -44,6 +44,7 @@ struct TdGemmParams {
   const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
   int ragged_rows = 64;                        // filled by the launcher: tiles with at most this many rows take the ragged loop (0 with TD_GEMM_NO_RAGGED: A/B)
+  int tail_first_wg = 0;                       // filled by the launcher (tail-split launches): workgroups from here on take a sub-tile of the last tiles
 };
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);

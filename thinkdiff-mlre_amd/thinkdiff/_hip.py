@@ -542,3 +542,19 @@ def sample_top_p(logits, temperature, top_p, seed, offset, out=None):
     check(lib().td_sample_top_p_bf16(ptr(x), x.stride(0), x.shape[0], x.shape[1], float(temperature), float(top_p),
                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFFFFFFFFFF, ptr(out), stream_ptr()))
     return out
+
+
+def kernel_source_digest() -> str:
+    """sha256 over the kernel sources of this tree (csrc/*.hip, csrc/*.h, include/thinkdiff_hip.h; names and contents, sorted): parity records
+    written on the GPU box carry it, and bench.py quotes a record only when it was measured on the sources it is running."""
+    import glob
+    import hashlib
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(pkg), "include", "thinkdiff_hip.h"))
+    h = hashlib.sha256()
+    for fn in files:
+        h.update(os.path.basename(fn).encode() + b"\0")
+        with open(fn, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
