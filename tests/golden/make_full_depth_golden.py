@@ -49,7 +49,7 @@ def lvlm_stage():
     ids = torch.tensor(rq["prompt_ids"] + rq["forced_ids"])
     n_p, n_o = len(rq["prompt_ids"]), len(rq["forced_ids"])
     emb = torch.nn.functional.embedding(ids, qsd["model.embed_tokens.weight"])
-    emb[torch.tensor(rq["prompt_ids"]) == C.IMAGE_PAD] = rq["vision_rows"]
+    emb[ids == C.IMAGE_PAD] = rq["vision_rows"]                  # (the forced ids are < 151 000: no placeholder among them)
     nxt = int(rq["position_ids"].max()) + 1                      # generation continues one past the largest prompt position (all three streams)
     pos = torch.cat([rq["position_ids"], (nxt + torch.arange(n_o, dtype=torch.int32))[None].expand(3, n_o)], dim=1)
     t0 = time.time()

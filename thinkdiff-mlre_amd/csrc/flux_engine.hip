@@ -770,6 +770,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const td_flux* root = f->parent ? f->parent : f;   // weights and precision live in the parent context
   const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
   // 8-bit attention: its pack pass reads the raw projections and applies QK-norm + RoPE itself (bit-identical, one HBM round trip less)
+  // A/B switches are read per call (tests flip them inside one process); three getenv per forward are noise next to ~600 launches
   const bool rope_in_pack = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_FUSE") == nullptr;      // (the switch: A/B timing and the bit-identity test)
   // 8-bit attention: every row's softmax starts from the reference its largest score of the PREVIOUS step gives (and leaves this step's for the next);
   // first steps, out-of-order steps and changed token layouts start from the first tile, as the stand-alone entry point does.  TD_ATTN8_NO_HREF: A/B.
@@ -778,7 +779,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const size_t href_blk = (size_t)H * S;
   int* const href_out = href_on ? f->href[f->href_cur ^ 1] : nullptr;
   const int* const href_in = href_read ? f->href[f->href_cur] : nullptr;
-  if (href_on) TD_CHECK_HIP(hipMemsetAsync(href_out, 0x80, (size_t)(L + Ls) * href_blk * 4, s));      // 0x80808080: far below any reference
+  // (href_out is cleared to 0x80808080 -- far below any reference -- block by block by the pack pass of each attention launch)
   // bf16 attention: the block's score bound as the softmax's fixed reference point (no row maxima, no rescales); TD_ATTN_NO_BOUND: the running-maximum form (A/B)
   const bool use_bound = root->attn_mode == TD_ATTENTION_BF16 && !root->bounds_dirty && getenv("TD_ATTN_NO_BOUND") == nullptr;
   const int q_int8 = root->precision == TD_PRECISION_INT8;

@@ -367,7 +367,7 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
 #pragma unroll
     for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / ((FP8 || I8) ? 2 * BK : BK);      // a k-tile is one 128-B row: 64 bf16 or 128 fp8 / int8
+  const int nt = p.probe == 2 ? 1 : p.K / ((FP8 || I8) ? 2 * BK : BK);      // a k-tile is one 128-B row: 64 bf16 or 128 fp8 / int8
 #pragma unroll
   for (int s = 0; s < NS; ++s) stage_one(s, 0, 0, 0);
   if constexpr (FP8) {
@@ -576,7 +576,7 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
 
   // ---- epilogue: lane owns NV contiguous columns of row (lane&15) of each m-tile -------------
   const int nbeg = n0 + wc * 16 * WN + (lane >> 4) * NV;
-  if (nbeg >= p.N) return;
+  if (nbeg >= p.N || p.probe == 1) return;      // (probe 1: a run-time condition, so the k-loop stays; nothing else is added to the kernel)
   const bool second = (p.C2 != nullptr) && (n0 >= p.n_split);
   const int act = second ? p.act2 : p.act;
   const int mbeg = m0 + wr * 16 * WM + frow;
@@ -704,6 +704,7 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   p.tiles_m = p.tiles_m0 + (p.g_M > 0 ? (p.g_M + BM - 1) / BM : 0);
   p.tiles_n = (p.N + BN - 1) / BN;
   p.ragged_rows = getenv("TD_GEMM_NO_RAGGED") ? 0 : 64;      // (A/B switch of the ragged-tile loop; read per launch so one process can time both)
+  if (const char* pr = getenv("TD_GEMM_PROBE")) p.probe = atoi(pr);
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   int grid = p.tiles_m * p.tiles_n;
   if constexpr (TAIL == 1 && WM == 8 && WN == 4 && !CONV) {      // the 256 x 256 tile of the block Linears: see whether its last round is worth cutting up

@@ -53,6 +53,17 @@ struct td_qwen2 {
   bf16_t* kvtmp = nullptr;   // [ws_rows, 2 Hkv 128] k|v rows of a batched step before they are scattered to their sequences
   bf16_t* lastrows = nullptr; // [MAX_BATCH, D] last-token rows of a batched prefill (lm_head input)
   int* ibuf = nullptr;       // device ints: kv lengths, scatter offsets
+  // Decode-step graphs.  A decode step is ~8 small launches per layer (230 for 28 layers) whose grids and arguments depend on the batch size
+  // only -- sequence lengths and cache rows are device ints (ibuf), tokens / positions / outputs go through the fixed buffers below -- so the
+  // step is captured once per (batch size, logits wanted) on the engine's own stream and replayed as ONE hipGraphLaunch on the caller's stream:
+  // the GPU then runs the step's kernels back to back instead of waiting ~6 us for the host between them (the step was launch-bound: 1.5 ms
+  // at one sequence of the 2B shape against 0.4 ms of weight streaming).  TD_QWEN2_NO_GRAPH: A/B and bisecting.
+  std::unordered_map<int, hipGraphExec_t> step_graphs;
+  std::unordered_map<int, int> step_calls;      // calls seen per key: the first runs eagerly (one-time function attributes are set outside a capture)
+  hipStream_t capture_stream = nullptr;
+  bool graphs_ok = true;
+  int *tok_buf = nullptr, *pos_buf = nullptr;   // [MAX_BATCH], [3, MAX_BATCH]: the step's token and position ids
+  bf16_t* logits_buf = nullptr;                 // [MAX_BATCH, vocab]
 };
 
 namespace {
@@ -197,6 +208,7 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
       {(void**)&f->attn, n * Hq * 128 * 2}, {(void**)&f->gu, n * 2 * I * 2}, {(void**)&f->act, n * I * 2},
       {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
       {(void**)&f->kvtmp, n * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4}, {(void**)&f->lastrows, (int64_t)MAX_BATCH * D * 2},
+      {(void**)&f->tok_buf, MAX_BATCH * 4}, {(void**)&f->pos_buf, 3 * MAX_BATCH * 4}, {(void**)&f->logits_buf, (int64_t)MAX_BATCH * cfg->vocab * 2},
   };
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
@@ -215,8 +227,16 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
   return TD_OK;
 }
 
+static void drop_step_graphs(td_qwen2* f) {
+  for (auto& kv : f->step_graphs) (void)hipGraphExecDestroy(kv.second);
+  f->step_graphs.clear();
+  f->step_calls.clear();
+}
+
 void td_qwen2_destroy(td_qwen2* f) {
   if (!f) return;
+  drop_step_graphs(f);
+  if (f->capture_stream) (void)hipStreamDestroy(f->capture_stream);
   (void)hipFree(f->arena);
   (void)hipFree(f->ws);
   delete f;
@@ -362,6 +382,7 @@ int td_qwen2_set_slots(td_qwen2* f, int n_slots) {
   TD_CHECK_ARG(f && n_slots >= 1 && n_slots <= f->max_tokens, "td_qwen2_set_slots: bad slot count %d", n_slots);
   f->n_slots = n_slots;
   f->slot_len = f->max_tokens / n_slots < f->ws_rows ? f->max_tokens / n_slots : f->ws_rows;
+  drop_step_graphs(f);      // the captured steps carry the old slot stride
   return TD_OK;
 }
 
@@ -377,29 +398,20 @@ int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream) {
   return TD_OK;
 }
 
-// One new token for each of the sequences in slots 0 .. B-1 (B <= 64): token_ids int32[B], position_ids int32[3,B] (device),
-// cache_pos[b] = tokens already in slot b (HOST ints).  hidden_out bf16[B,hidden], logits bf16[B,vocab] (either may be NULL).
-int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
-                          void* hidden_out, void* logits, void* stream) {
-  TD_CHECK_ARG(f && token_ids && position_ids && cache_pos, "td_qwen2_decode_batch: null argument");
-  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && B <= f->ws_rows, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots, %d workspace rows)", B, MAX_BATCH, f->n_slots, f->ws_rows);
-  hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+// The launches of one decode step for the sequences in slots 0 .. B-1: ids from tok_buf / pos_buf, lengths and cache rows from ibuf, the final
+// hidden states left in xn and the logits in logits_buf.  Captured into a graph by td_qwen2_decode_batch (nothing here may depend on a host value
+// other than B and the engine's own pointers; max_len only sizes the generic attention entry's bookkeeping, the decode kernel reads kv_lens).
+int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s) {
   const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
-  IntPack ip;
-  int max_len = 0;
-  for (int b = 0; b < B; ++b) {
-    TD_CHECK_ARG(cache_pos[b] >= 0 && cache_pos[b] < f->slot_len, "td_qwen2_decode_batch: sequence %d is full (%d of %d)", b, cache_pos[b], f->slot_len);
-    ip.v[b] = cache_pos[b] + 1;                                         // keys visible to the new token
-    ip.v[MAX_BATCH + b] = (b * f->slot_len + cache_pos[b]) * KVW;       // its cache row (elements)
-    max_len = cache_pos[b] + 1 > max_len ? cache_pos[b] + 1 : max_len;
-  }
-  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, f->ibuf, ip, 2 * MAX_BATCH);
   const int* kv_lens = f->ibuf;
   const int* row_off = f->ibuf + MAX_BATCH;
 
-  TDQ_TRY(td_embed_gather_launch(token_ids, f->embed_w, f->h, B, D, f->cfg.vocab, s));
-  TDQ_TRY(td_mrope_table_launch(position_ids, B, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
+  TDQ_TRY(td_embed_gather_launch(f->tok_buf, f->embed_w, f->h, B, D, f->cfg.vocab, s));
+  TDQ_TRY(td_mrope_table_launch(f->pos_buf, B, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
   TdNormParams np;
   np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = B; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
   for (int i = 0; i < f->cfg.num_layers; ++i) {
@@ -437,13 +449,72 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
   }
   np.w = f->norm_w; np.y = f->xn;
   TDQ_TRY(td_norm_rows_launch(np, s));
-  if (hidden_out) TD_CHECK_HIP(hipMemcpyAsync(hidden_out, f->xn, (size_t)B * D * 2, hipMemcpyDeviceToDevice, s));
-  if (logits) {
+  if (want_logits) {
     TdGemmParams g;
-    g.A = f->xn; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
+    g.A = f->xn; g.lda = D; g.W = f->lm_w; g.C = f->logits_buf; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
     TDQ_TRY(td_gemm_launch(g, s));
   }
   TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// One new token for each of the sequences in slots 0 .. B-1 (B <= 64): token_ids int32[B], position_ids int32[3,B] (device),
+// cache_pos[b] = tokens already in slot b (HOST ints).  hidden_out bf16[B,hidden], logits bf16[B,vocab] (either may be NULL).
+int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
+                          void* hidden_out, void* logits, void* stream) {
+  TD_CHECK_ARG(f && token_ids && position_ids && cache_pos, "td_qwen2_decode_batch: null argument");
+  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && B <= f->ws_rows, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots, %d workspace rows)", B, MAX_BATCH, f->n_slots, f->ws_rows);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
+  const int QW = Hq * 128, KVW = 2 * Hkv * 128;
+  IntPack ip;
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) {
+    TD_CHECK_ARG(cache_pos[b] >= 0 && cache_pos[b] < f->slot_len, "td_qwen2_decode_batch: sequence %d is full (%d of %d)", b, cache_pos[b], f->slot_len);
+    ip.v[b] = cache_pos[b] + 1;                                         // keys visible to the new token
+    ip.v[MAX_BATCH + b] = (b * f->slot_len + cache_pos[b]) * KVW;       // its cache row (elements)
+    max_len = cache_pos[b] + 1 > max_len ? cache_pos[b] + 1 : max_len;
+  }
+  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, f->ibuf, ip, 2 * MAX_BATCH);
+  TD_CHECK_LAUNCH();
+  // the step reads its ids from fixed buffers and leaves its outputs in fixed buffers (the captured form needs stable addresses)
+  TD_CHECK_HIP(hipMemcpyAsync(f->tok_buf, token_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  TD_CHECK_HIP(hipMemcpyAsync(f->pos_buf, position_ids, (size_t)3 * B * 4, hipMemcpyDeviceToDevice, s));
+  const bool want_logits = logits != nullptr;
+  const int key = 2 * B + (want_logits ? 1 : 0);
+  static const bool no_graph = getenv("TD_QWEN2_NO_GRAPH") != nullptr;
+  auto it = f->step_graphs.find(key);
+  if (it != f->step_graphs.end()) {
+    TD_CHECK_HIP(hipGraphLaunch(it->second, s));
+  } else if (no_graph || !f->graphs_ok || f->step_calls[key]++ == 0) {
+    TDQ_TRY(decode_step(f, B, max_len, want_logits, s));
+  } else {
+    // capture on the engine's own stream (the caller's may be the legacy default stream, which cannot capture), after everything the caller
+    // queued so far: nothing runs during a capture, but the eager fallback below must see the ids copied above
+    if (!f->capture_stream) TD_CHECK_HIP(hipStreamCreateWithFlags(&f->capture_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(f->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int rc = decode_step(f, B, max_len, want_logits, f->capture_stream);
+      ok = hipStreamEndCapture(f->capture_stream, &graph) == hipSuccess && rc == TD_OK && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ok) {
+      f->step_graphs[key] = exec;
+      TD_CHECK_HIP(hipGraphLaunch(exec, s));
+    } else {
+      (void)hipGetLastError();
+      f->graphs_ok = false;      // this runtime cannot capture the step: stay on the eager path for good
+      TDQ_TRY(decode_step(f, B, max_len, want_logits, s));
+    }
+  }
+  if (hidden_out) TD_CHECK_HIP(hipMemcpyAsync(hidden_out, f->xn, (size_t)B * D * 2, hipMemcpyDeviceToDevice, s));
+  if (logits) TD_CHECK_HIP(hipMemcpyAsync(logits, f->logits_buf, (size_t)B * f->cfg.vocab * 2, hipMemcpyDeviceToDevice, s));
   return TD_OK;
 }
 

@@ -45,6 +45,7 @@ struct TdGemmParams {
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
   int ragged_rows = 64;                        // filled by the launcher: tiles with at most this many rows take the ragged loop (0 with TD_GEMM_NO_RAGGED: A/B)
   int tail_first_wg = 0;                       // filled by the launcher (tail-split launches): workgroups from here on take a sub-tile of the last tiles
+  int probe = 0;                               // filled by the launcher from TD_GEMM_PROBE (timing experiments, results WRONG): 1 = no epilogue, 2 = no k-loop
 };
 
 int td_gemm_launch(const TdGemmParams& p, hipStream_t stream);
@@ -94,7 +95,7 @@ struct TdAttnParams {
   // td_attn_fp8_launch only: reference points carried from one denoise step to the next (ints, [Hq][Sq]).  ref_in (may be null): where each row's
   // softmax starts -- ceil(the row's largest score of the PREVIOUS step) - headroom, in log2 units -- instead of the first tile's maximum, so that
   // the reference hardly ever has to move (a move rescales O, the row sums and the scores: ~80 VALU instructions per wave); ref_out (may be null):
-  // receives the same quantity of THIS launch (atomic max: both owners of a split item contribute), to be preset to INT_MIN-like values by the caller.
+  // receives the same quantity of THIS launch (atomic max: both owners of a split item contribute); the launch's pack pass presets it.
   const int* ref_in = nullptr; int* ref_out = nullptr;
   // td_attn_fp8_launch only (rope_cos != null): Q / K are the RAW projection outputs and the pack pass applies the per-head
   // QK-RMSNorm + interleaved-pair rotary embedding of td_qk_norm_rope_kernel on its way (same arithmetic, same summation order and

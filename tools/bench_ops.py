@@ -117,6 +117,42 @@ def bench_gemmfp8():
     print("sustained FLUX-step GEMM mix (3 s windows): " + " | ".join(f"{k} " + " ".join(f"{v:6.0f}" for v in vs) + " TF/s" for k, vs in res.items()), flush=True)
 
 
+def bench_gemmprobe():
+    """Where a block GEMM's time goes: the whole launch, the k-loop alone (TD_GEMM_PROBE=1: no epilogue) and the prologue + epilogue alone
+    (TD_GEMM_PROBE=2: one k-tile), bf16 and int8, GELU epilogue, cold weights, tail split off and on."""
+    for name, M, N, K in [("ff1", 4289, 12288, 3072), ("qkv", 4289, 9216, 3072), ("single_in", 4289, 21504, 3072), ("ff1 T=258", 4354, 12288, 3072)]:
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        npool = max(2, int(0.8e9 // (N * K * 2)))
+        pool = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(npool)]
+        ipool = [_hip.quant_rows_int8(w) for w in pool]
+        xi, xis = _hip.quant_rows_int8(x)
+        b = torch.randn(N, device="cuda").bfloat16()
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        st = {"i": 0}
+        def f_bf16():
+            st["i"] = (st["i"] + 1) % npool
+            _hip.linear_grouped2(x, pool[st["i"]], b, y, None, None, None, None, act=_hip.ACT_GELU_TANH, tile_cfg=0)
+        def f_int8():
+            st["i"] = (st["i"] + 1) % npool
+            wq, ws = ipool[st["i"]]
+            _hip.linear_int8(xi, xis, wq, ws, b, act=_hip.ACT_GELU_TANH, out=y, tile_cfg=0)
+        for tail in ("off", "on"):
+            if tail == "off":
+                os.environ["TD_GEMM_NO_TAIL"] = "1"
+            else:
+                os.environ.pop("TD_GEMM_NO_TAIL", None)
+            row = []
+            for kind, f in (("bf16", f_bf16), ("int8", f_int8)):
+                t = {}
+                for probe in ("0", "1", "2"):
+                    os.environ["TD_GEMM_PROBE"] = probe
+                    t[probe] = min(timeit(f, iters=10, warmup=2) for _ in range(3))
+                os.environ.pop("TD_GEMM_PROBE")
+                row.append(f"{kind}: whole {t['0']*1e3:6.1f} us  k-loop only {t['1']*1e3:6.1f}  1 k-tile + epilogue {t['2']*1e3:6.1f}")
+            print(f"{name:10s} M={M} N={N} K={K} tail split {tail:3s} | " + " | ".join(row), flush=True)
+        del pool, ipool
+
+
 def bench_gemmepi():
     """The six block GEMMs of a FLUX step with their real epilogues (bias / GELU / gate + residual / split output), cold weights."""
     S = 4289
