@@ -228,6 +228,34 @@ def test_full_depth_8bit_policies_on_the_stress_checkpoint(full_model):
         assert res[shipped]["pixel_rmse_vs_oracle"] < 1e-2, f"{shipped}: {res[shipped]['pixel_rmse_vs_oracle']:.4f} on the stress fixture"
 
 
+def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
+    """Full size, 3 denoise steps per policy: the persistent form and the tail split of the 256 x 256 GEMM tile (csrc/gemm_bf16.hip) against the plain
+    one-tile-per-workgroup launch -- bit-identical latents in bf16, int8 (dynamic and history scales: the int8-output epilogue) and with the e4m3 attention."""
+    fx = _fixture("cfg5_T258")
+    assert fx["weights_checksum"] == full_model.ensure("plain")
+    pipe = full_model.pipe
+    raw, pe, pool = C.pipeline_inputs(fx["T"], fx["seed"], device="cuda")
+    lat = R.pack_latents(raw.cpu()).cuda()
+    tr = pipe.transformer
+
+    def run(prec):
+        tr.set_precision(prec.split("_")[0], act_scales="history" if "_history" in prec else "dynamic")
+        tr.set_attention("fp8" if prec.endswith("_attn8") else "bf16")
+        out = pipe(prompt_embeds=pe, pooled_prompt_embeds=pool, height=1024, width=1024, num_inference_steps=3, guidance_scale=3.5,
+                   latents=lat, output_type="latent").images[0].clone()
+        torch.cuda.synchronize()
+        return out
+    for prec in ("bf16", "int8", "int8_history", "int8_history_attn8"):
+        monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
+        monkeypatch.setenv("TD_GEMM_NO_PERSIST", "1")
+        base = run(prec)
+        monkeypatch.delenv("TD_GEMM_NO_TAIL")
+        monkeypatch.delenv("TD_GEMM_NO_PERSIST")
+        assert torch.equal(run(prec), base), f"{prec}: the persistent / tail-split GEMM launches changed the latents"
+    tr.set_precision("bf16")
+    tr.set_attention("bf16")
+
+
 def test_config3_lvlm_full_size_vs_oracle_fixture(full_model):
     """BASELINE config 3 at full size (reference scripts/test/test_mllama_t5_decoder_flux.py:143-196, configs/test_thinkdiff_lvlm_ccsbu_image_text.yaml:24-35):
     a 28-layer Qwen2-VL-7B-shaped decoder (7.6 B parameters, regenerated on the device) takes one image + instruction request -- 103 prompt rows with

@@ -13,6 +13,7 @@
 // layer's KV cache rows (dual-output GEMM epilogue), so prefill and decode share one code path:
 // `td_qwen2_forward(tokens at positions [pos0, pos0+n))` attends over cache rows [0, pos0+n).
 // Parameters are addressed by their Hugging Face names (model.layers.N.self_attn.q_proj.weight, ...).
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -504,6 +505,7 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
     }
     if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
     if (graph) (void)hipGraphDestroy(graph);
+    if (getenv("TD_QWEN2_GRAPH_DEBUG")) fprintf(stderr, "td_qwen2_decode_batch: step graph for B=%d logits=%d %s\n", B, (int)want_logits, ok ? "captured" : "NOT captured (eager from now on)");
     if (ok) {
       f->step_graphs[key] = exec;
       TD_CHECK_HIP(hipGraphLaunch(exec, s));
