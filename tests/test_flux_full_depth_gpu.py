@@ -229,8 +229,8 @@ def test_full_depth_8bit_policies_on_the_stress_checkpoint(full_model):
 
 
 def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
-    """Full size, 3 denoise steps per policy: the persistent form and the tail split of the 256 x 256 GEMM tile (csrc/gemm_bf16.hip) against the plain
-    one-tile-per-workgroup launch -- bit-identical latents in bf16, int8 (dynamic and history scales: the int8-output epilogue) and with the e4m3 attention."""
+    """Full size, 3 denoise steps per policy: the tail split of the 256 x 256 GEMM tile (csrc/gemm_bf16.hip) against the plain one-tile-per-workgroup
+    launch -- bit-identical latents in bf16, int8 (dynamic and history scales: the int8-output epilogue) and with the e4m3 attention."""
     fx = _fixture("cfg5_T258")
     assert fx["weights_checksum"] == full_model.ensure("plain")
     pipe = full_model.pipe
@@ -247,11 +247,9 @@ def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
         return out
     for prec in ("bf16", "int8", "int8_history", "int8_history_attn8"):
         monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
-        monkeypatch.setenv("TD_GEMM_NO_PERSIST", "1")
         base = run(prec)
         monkeypatch.delenv("TD_GEMM_NO_TAIL")
-        monkeypatch.delenv("TD_GEMM_NO_PERSIST")
-        assert torch.equal(run(prec), base), f"{prec}: the persistent / tail-split GEMM launches changed the latents"
+        assert torch.equal(run(prec), base), f"{prec}: the tail-split GEMM launches changed the latents"
     tr.set_precision("bf16")
     tr.set_attention("bf16")
 
@@ -261,7 +259,8 @@ def test_config3_lvlm_full_size_vs_oracle_fixture(full_model):
     a 28-layer Qwen2-VL-7B-shaped decoder (7.6 B parameters, regenerated on the device) takes one image + instruction request -- 103 prompt rows with
     64 spliced vision tokens and 2-D M-RoPE streams -- and is teacher-forced through max_tokens = min_tokens = 128 KV-cached decode steps;
     `model.norm` hidden states of the output tokens -> aligner (fp32 T5LayerNorm) -> prompt_embeds [1, 128, 4096] -> FLUX 1024 x 1024, 28 steps,
-    guidance 3.5 (T = 128, S = 4224) -> VAE -> uint8, all against tests/golden/full_depth_cfg3_lvlm7b.pt."""
+    guidance 3.5 (T = 128, S = 4224) -> VAE -> uint8, all against tests/golden/full_depth_cfg3_lvlm7b.pt.  Bars: pixels <= 1e-2 RMSE (the north-star
+    bar); decoder hidden states no further from exact arithmetic than 1.5 x the bf16 oracle is (the fixture carries both)."""
     from oracle import aligner_ref as A
     from oracle import qwen2vl_ref as Q
     from thinkdiff.models.mllama_vllm_t5_embed_decoder_2 import MllamaVllmT5EmbedDecoderForConditionalGeneration_5
@@ -289,6 +288,11 @@ def test_config3_lvlm_full_size_vs_oracle_fixture(full_model):
     g = m.mllama.generate(rq["prompt_ids"], m.mllama_sampling_params, position_ids=rq["position_ids"], inputs_embeds=emb, forced_output_ids=rq["forced_ids"])
     torch.cuda.synchronize()
     e_p, e_o = _rel_rmse(g["prompt_hidden_states"], fx["prompt_hidden"]), _rel_rmse(g["hidden_states"], fx["output_hidden"])
+    # ... and against the same graph in exact arithmetic (tests/golden/add_lvlm_fp32_reference.py): 28 random-weight layers amplify rounding noise, so
+    # two correct bf16 implementations end up several per cent apart; what a correct engine cannot be is further from the exact result than the bf16
+    # oracle itself is (x 1.5: the criterion of tests/test_qwen2_gpu.py at small size)
+    x_p, x_o = _rel_rmse(g["prompt_hidden_states"], fx["prompt_hidden_fp32"]), _rel_rmse(g["hidden_states"], fx["output_hidden_fp32"])
+    r_p, r_o = _rel_rmse(fx["prompt_hidden"], fx["prompt_hidden_fp32"]), _rel_rmse(fx["output_hidden"], fx["output_hidden_fp32"])
     assert g["hidden_states"].shape == (128, qcfg.hidden) and g["token_ids"] == rq["forced_ids"]
     # the product call: get_embed(output_embed) = hidden states of the 128 output tokens through the aligner
     t0 = time.time()
@@ -296,8 +300,9 @@ def test_config3_lvlm_full_size_vs_oracle_fixture(full_model):
     torch.cuda.synchronize()
     t_embed = time.time() - t0
     assert embs[0].shape == (128, 4096) and texts == [" ".join(map(str, rq["forced_ids"]))]
-    e_a = _rel_rmse(embs[0], fx["aligner_out"])
-    print(f"[config 3] hidden states vs the oracle: prompt {e_p:.4f}, 128 output tokens {e_o:.4f}; aligner output {e_a:.4f}; get_embed {t_embed:.2f} s")
+    e_a, x_a, r_a = _rel_rmse(embs[0], fx["aligner_out"]), _rel_rmse(embs[0], fx["aligner_out_fp32"]), _rel_rmse(fx["aligner_out"], fx["aligner_out_fp32"])
+    print(f"[config 3] hidden states, HIP vs the bf16 oracle: prompt {e_p:.4f}, 128 output tokens {e_o:.4f}, aligner output {e_a:.4f}; HIP vs exact arithmetic: "
+          f"{x_p:.4f}, {x_o:.4f}, {x_a:.4f}; the bf16 oracle vs exact arithmetic: {r_p:.4f}, {r_o:.4f}, {r_a:.4f}; get_embed {t_embed:.2f} s")
     # sampled (not forced) generation at the config's temperature / top-p: 128 tokens, finite hidden states (the reference samples; parity is teacher-forced)
     smp = m.mllama.generate(rq["prompt_ids"], m.mllama_sampling_params, position_ids=rq["position_ids"], inputs_embeds=emb, generator=torch.Generator(device="cuda").manual_seed(42))
     assert len(smp["token_ids"]) == 128 and torch.isfinite(smp["hidden_states"].float()).all()
@@ -316,9 +321,11 @@ def test_config3_lvlm_full_size_vs_oracle_fixture(full_model):
     px = _px_rmse(u8, fx["image_u8"])
     print(f"[config 3] FLUX 1024^2 T=128 on the aligner output: latent rel-RMSE per step {', '.join(f'{s}: {e:.4f}' for s, e in errs.items())}; pixel RMSE {px:.5f}")
     _record("config3_lvlm7b_vs_oracle", {"prompt_hidden_rel_rmse": e_p, "output_hidden_rel_rmse": e_o, "aligner_out_rel_rmse": e_a, "get_embed_seconds": t_embed,
+                                         "vs_exact_arithmetic": {"hip": [x_p, x_o, x_a], "bf16_oracle": [r_p, r_o, r_a]},
                                          "latent_rel_rmse": errs, "pixel_rmse": px, "oracle_seconds": fx["oracle_seconds"]})
-    assert e_p < 2e-2 and e_o < 2e-2, "Qwen2-VL-7B-shaped decoder hidden states left the 2e-2 bar"
-    assert e_a < 3e-2
+    for name, x, r in (("prompt hidden states", x_p, r_p), ("output hidden states", x_o, r_o), ("aligner output", x_a, r_a)):
+        assert x < 1.5 * r + 2e-3, f"config 3 {name}: HIP is {x:.4f} from exact arithmetic, the bf16 oracle only {r:.4f}"
+    assert max(e_p, e_o, e_a) < 2.5 * max(r_p, r_o, r_a), "HIP and the bf16 oracle are further apart than two bf16 roundings of the same graph can be"
     assert px < 1e-2, f"config 3 pixels {px:.4f} from the oracle fixture exceed the 1e-2 bar"
 
 

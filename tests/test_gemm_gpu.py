@@ -165,16 +165,13 @@ def test_linear_grouped_ragged_text_rows(hip, cfg):
     _close(d1, _ref_linear(x1, w1, b1, act=1), 2.0 ** -6)
 
 
-@pytest.mark.parametrize("split,persist", [("auto", True), ("2", True), ("4", True), ("auto", False), ("off", True)])
+@pytest.mark.parametrize("split", ["auto", "2", "4"])
 @pytest.mark.parametrize("M0,M1,N,K", [(4096, 193, 12288, 256), (4096, 258, 9216, 128), (4354, 0, 21504, 128), (4096, 193, 4352, 512)])
-def test_linear_tail_split_and_persistent_form_are_bit_identical(hip, monkeypatch, M0, M1, N, K, split, persist):
-    """Launch forms of the 256 x 256 tile (csrc/gemm_bf16.hip) that change WHO computes a tile and WHEN, never WHAT:
-      * tail split -- tile counts that leave a mostly empty last round of the 256 CUs (816 = 3.19 rounds, 648 = 2.5, 1 512 = 5.9 with ragged
-        tiles, 289): the last tiles are cut into 2 or 4 row sub-tiles;
-      * persistent form -- with two or more full rounds, one workgroup per CU walks the full rounds' tiles and issues the next tile's first
-        operand transfers from inside the running tile's epilogue.
-    Every output element is still one workgroup's full contraction in the same order, so each form must equal the plain one-tile-per-workgroup
-    launch BIT FOR BIT -- with the grouped two-problem form, ragged last tiles, the gate / residual and GELU epilogues, int8 and e4m3 operands."""
+def test_linear_tail_split_is_bit_identical(hip, monkeypatch, M0, M1, N, K, split):
+    """Tile counts that leave a mostly empty last round of the 256 CUs (816 = 3.19 rounds, 648 = 2.5, 1 512 = 5.9 with ragged tiles, 289): the launcher
+    cuts the last tiles into 2 or 4 row sub-tiles (csrc/gemm_bf16.hip, TAIL).  Every output element is still one workgroup's full contraction, so the
+    result must equal the unsplit launch BIT FOR BIT -- with the grouped two-problem form, ragged last tiles, the gate / residual and GELU epilogues,
+    int8 and e4m3 operands."""
     g = torch.Generator().manual_seed(M0 + N + K)
     mk = lambda *s: torch.randn(*s, generator=g).bfloat16()
     x0, w0, b0, g0, h0 = mk(M0, K).cuda(), (mk(N, K).float() * 0.05).bfloat16().cuda(), mk(N).cuda(), mk(N).cuda(), mk(M0, N).cuda()
@@ -195,14 +192,10 @@ def test_linear_tail_split_and_persistent_form_are_bit_identical(hip, monkeypatc
         torch.cuda.synchronize()
         return d0, d1, e0, y8, yf
     monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
-    monkeypatch.setenv("TD_GEMM_NO_PERSIST", "1")
     base = run()
-    if split != "off":
-        monkeypatch.delenv("TD_GEMM_NO_TAIL")
-    if split in ("2", "4"):
+    monkeypatch.delenv("TD_GEMM_NO_TAIL")
+    if split != "auto":
         monkeypatch.setenv("TD_GEMM_TAIL", split)
-    if persist:
-        monkeypatch.delenv("TD_GEMM_NO_PERSIST")
     got = run()
     for a, b in zip(got, base):
         if a is not None:

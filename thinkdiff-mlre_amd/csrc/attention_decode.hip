@@ -52,9 +52,8 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
     for (int i = 0; i < 8; ++i) o[g][i] = 0.f;
   }
   const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
-  for (int key = slot; key < len; key += 16) {
-    const u32x4_t kk = *(const u32x4_t*)(Kb + (size_t)key * p.ldkv);
-    const u32x4_t vv = *(const u32x4_t*)(Vb + (size_t)key * p.ldkv);
+  // one key of this slot: scores of the G query heads against it, online softmax, value accumulation
+  auto one_key = [&](const u32x4_t& kk, const u32x4_t& vv) {
     float vf[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { vf[2 * i] = bf_lo(vv[i]); vf[2 * i + 1] = bf_hi(vv[i]); }
@@ -71,6 +70,26 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[g][i] = o[g][i] * corr + pe * vf[i];
     }
+  };
+  // The loop is a chain of dependent HBM / L2 round trips (one key row per slot and trip: ~0.6 us each, 19 trips for 300 keys = the 12 us the
+  // kernel took per layer at one sequence): four keys per slot are fetched before the first is used, so a trip's latency covers four keys.
+  // The keys of a slot are still visited in increasing order, so the arithmetic -- and the result -- is unchanged.
+  constexpr int UN = 4;
+  int key = slot;
+  for (; key + 16 * (UN - 1) < len; key += 16 * UN) {
+    u32x4_t kk[UN], vv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      kk[u] = *(const u32x4_t*)(Kb + (size_t)(key + 16 * u) * p.ldkv);
+      vv[u] = *(const u32x4_t*)(Vb + (size_t)(key + 16 * u) * p.ldkv);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) one_key(kk[u], vv[u]);
+  }
+  for (; key < len; key += 16) {
+    const u32x4_t kk = *(const u32x4_t*)(Kb + (size_t)key * p.ldkv);
+    const u32x4_t vv = *(const u32x4_t*)(Vb + (size_t)key * p.ldkv);
+    one_key(kk, vv);
   }
   // merge the 4 key slots of this wave (lanes 16 / 32 apart hold the same d-chunk), then the 4 waves through LDS
 #pragma unroll

@@ -59,13 +59,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 // `act` and `mode` are block-uniform run-time values: ONE body, with scalar branches around the optional stages of a row.
 // (One instantiation per activation, selected by a switch in front, made the compiler hoist the shared `acc + bias` of all
 // WM rows above the switch: 128 extra live values and a spilling kernel.)
-// `hook` runs once, under the caller's full EXEC mask, between the per-column operand loads and the rows' arithmetic and stores: the persistent
-// form issues the NEXT tile's first LDS-DMA transfers there (nothing the rows wait for is then queued behind those transfers -- vector-memory
-// operations of a wave complete in order).  `live` = this lane owns output columns (false only past N in a last, partial column tile).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int WM, int WN, bool Q8 = false, class Hook = NoHook>   // mode 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
+template <int WM, int WN, bool Q8 = false>   // mode 0: bias(+act); 1: bias, gate, (+res); 2: bias, res
 __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView& p, f32x4_t (&acc)[WN][WM], int mbeg, int nbeg, bool second,
-                                         const int act, const int mode, const bool live = true, Hook hook = Hook()) {
+                                         const int act, const int mode) {
   constexpr int NV = 4 * WN;
   constexpr int CH = (NV % 8 == 0) ? 8 : 4;          // columns per access: 16-byte accesses when the lane's span allows
   constexpr int NCH = NV / CH;
@@ -113,13 +109,6 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
         gate[c * 4] = bf_lo(g[0]); gate[c * 4 + 1] = bf_hi(g[0]); gate[c * 4 + 2] = bf_lo(g[1]); gate[c * 4 + 3] = bf_hi(g[1]);
       }
     }
-  }
-
-  // the rows' inverse scales of the int8 output form, loaded with the per-column operands (ahead of the hook)
-  float q8inv[Q8 ? WM : 1];
-  if constexpr (Q8) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) q8inv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsQi, (unsigned)(mbeg + i * 16) * 4u, 0, 0));
   }
 
   auto row = [&](const int i) {
@@ -170,7 +159,7 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
         for (int c = 0; c < NV; ++c) am = fmaxf(am, fabsf(v[c]));
         am = fmaxf(am, __shfl_xor(am, 16, 64));
         am = fmaxf(am, __shfl_xor(am, 32, 64));          // the row's maximum over this wave's 64 columns
-        const float inv = q8inv[i];
+        const float inv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsQi, (unsigned)m * 4u, 0, 0));
         u32x4_t o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -224,8 +213,6 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
       }
     }
   };
-  hook();
-  if (!live) return;
   // two halves: the scheduler may hoist the residual loads of one half ahead of its arithmetic, not those of all WM rows
   // (which is what ran the 256x256 kernel out of registers)
 #pragma unroll
@@ -624,241 +611,6 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
   epilogue<WM, WN, I8 && WN == 4>(p, pv, acc, mbeg, nbeg, second, act, mode);
 }
 
-// ---- persistent form of the main loop (bf16 / int8 operands, the 256 x 256 tile of the block Linears) ---------------------------------------
-// One workgroup per CU walks logical tiles first, first + stride, ... of [0, n_tiles): what a one-shot workgroup leaves exposed at its ends --
-// its dispatch, and the HBM latency of its first operand transfers with every CU asking at once (~9 k cycles per 96 KiB) -- happens here
-// while the PREVIOUS tile's epilogue runs: after the last k-tile one barrier frees the LDS ring, the next tile's first transfers (A k-tile 0,
-// W k-tiles 0 and 1) are issued from inside the epilogue (behind its operand loads, ahead of its arithmetic and stores), and the next k-loop
-// starts on operands that have landed.  The k-loop, the staging order and the epilogue are those of gemm_tile, instruction for instruction:
-// every output element is the same contraction in the same order, so the result is bit-identical to the one-shot launch.
-// At K = 3072 the int8 tile's k-loop is half as long as the bf16 one's (24 k-tiles) while the fixed part is the same: ~27 % of an int8
-// launch sat outside the k-loop (tools/bench_ops.py gemmprobe), which is what this form is for.
-template <int WM, int WN, bool I8>
-__device__ __forceinline__ void gemm_tiles_persistent(const TdGemmParams& p, char* smem, const int first, const int stride, const int n_tiles) {
-  constexpr int BM = 32 * WM, BN = 64 * WN;
-  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
-  constexpr int GA = BM / 8, GW = BN / 8;
-  constexpr int SA = (GA + 7) / 8, SW = (GW + 7) / 8;
-  constexpr int NV = 4 * WN;
-  constexpr unsigned ESZ = I8 ? 1u : 2u;
-  constexpr int NS = SA + SW;
-  constexpr int W_REGION = 2 * A_BYTES;
-  static_assert(GA % 8 == 0 && GW % 8 == 0, "persistent form: tile rows are whole multiples of 64");
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
-  const int srow = lane >> 3;
-  const int schunk = ((lane & 7) ^ srow) << 4;
-  const int frow = lane & 15;
-  const int foff0 = frow * ROW_BYTES + ((((lane >> 4)) ^ (lane & 7)) << 4);
-  const int aoff = (wr * 16 * WM) * ROW_BYTES;
-  const int woff = (wc * 16 * WN) * ROW_BYTES;
-  const int nt = p.probe == 2 ? 1 : p.K / (I8 ? 2 * BK : BK);
-
-  // Per-tile state: recomputed from the tile index wherever it is needed (the epilogue's hook builds the next tile's, uses it and drops it;
-  // the loop builds it again afterwards) -- a second copy kept live across the epilogue cost the int8 kernel its last registers.
-  struct Ctx {
-    bool second_prob; int m0, n0, M;
-    __amdgpu_buffer_rsrc_t rsA, rsW;
-    unsigned voffS[NS];
-  };
-  auto setup = [&](const int t, Ctx& c) {
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int gid = t / per_group;
-    const int first_m = gid * GROUP_M;
-    const int gsize = min(p.tiles_m - first_m, GROUP_M);
-    const int in_g = t - gid * per_group;
-    int tm = first_m + in_g % gsize;
-    const int tn = in_g / gsize;
-    c.second_prob = tm >= p.tiles_m0;
-    if (c.second_prob) tm -= p.tiles_m0;
-    c.m0 = tm * BM; c.n0 = tn * BN;
-    c.M = c.second_prob ? p.g_M : p.M;
-    const bf16_t* Aptr = c.second_prob ? p.g_A : p.A;
-    const bf16_t* Wptr = c.second_prob ? p.g_W : p.W;
-    c.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Aptr, 0, (unsigned)(((long long)(c.M - 1) * p.lda + p.K) * ESZ), 0x00020000);
-    c.rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wptr, 0, (unsigned)((long long)p.N * p.K * ESZ), 0x00020000);
-#pragma unroll
-    for (int s = 0; s < SA; ++s) c.voffS[s] = (unsigned)(c.m0 + (wid + 8 * s) * 8 + srow) * (unsigned)p.lda * ESZ + schunk;
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
-      const int rho = (wid + 8 * s) * 8 + srow;         // LDS row of the block's W slab (gemm_tile)
-      const int wcol = rho / (16 * WN);
-      const int rem = rho - wcol * (16 * WN);
-      const int j = rem >> 4, i16 = rem & 15;
-      c.voffS[SA + s] = (unsigned)(c.n0 + wcol * (16 * WN) + (i16 >> 2) * NV + j * 4 + (i16 & 3)) * (unsigned)p.K * ESZ + schunk;
-    }
-  };
-  auto lds_of = [&](int s) { return (wid + 8 * (s < SA ? s : s - SA)) * 1024; };      // wave-uniform
-  auto stage_one = [&](const Ctx& c, int s, int abuf, int wbuf, int kt) {
-    if (s < SA) __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (TD_LDS void*)(smem + abuf * A_BYTES + lds_of(s)), 16, c.voffS[s], kt * (BK * 2), 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (TD_LDS void*)(smem + W_REGION + wbuf * W_BYTES + lds_of(s)), 16, c.voffS[s], kt * (BK * 2), 0, 0);
-  };
-  auto prologue = [&](const Ctx& c) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) stage_one(c, s, 0, 0, 0);
-#pragma unroll
-    for (int s = SA; s < NS; ++s) stage_one(c, s, 0, 1, min(1, nt - 1));
-  };
-  auto is_ragged = [&](const Ctx& c) { return WM >= 8 && c.M - c.m0 <= p.ragged_rows; };
-
-  Ctx cur;
-  int t = first;
-  if (t >= n_tiles) return;
-  setup(t, cur);
-  bool staged = false;
-  while (true) {
-    const int t_next = t + stride;
-    const bool more = t_next < n_tiles;
-    if (is_ragged(cur)) {
-      // a tile with at most 64 rows: the self-contained one-shot body (its own staging protocol); the ring is drained before it is reused
-      gemm_tile<WM, WN, false, false, I8>(p, smem, cur.second_prob, cur.m0, cur.n0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      staged = false;
-      if (!more) return;
-      setup(t_next, cur);
-      t = t_next;
-      continue;
-    }
-    if (!staged) prologue(cur);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the transfers issued from inside the previous epilogue (and that epilogue's stores behind them)
-
-    f32x4_t acc[WN][WM];
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // ---- the k-loop of gemm_tile's main path -------------------------------------------------------------------------------------------
-    int wcur = 0;
-    for (int kt0 = 0; kt0 < nt; ++kt0) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW) : "memory");
-      __builtin_amdgcn_s_barrier();
-      const char* wb = smem + W_REGION + wcur * W_BYTES + woff;
-      const char* ab = smem + (kt0 & 1) * A_BYTES + aoff;
-      const int kt_a = min(kt0 + 1, nt - 1);
-      const int kt_w = min(kt0 + 2, nt - 1);
-      const int abuf_next = (kt0 + 1) & 1;
-      const int wbuf_next = wcur == 0 ? 2 : wcur - 1;
-      wcur = wcur == 2 ? 0 : wcur + 1;
-      bf16x8_t wf[2][WN], af[2];
-#pragma unroll
-      for (int j = 0; j < WN; ++j) wf[0][j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + foff0);
-      af[0] = *(const bf16x8_t*)(ab + foff0);
-      __builtin_amdgcn_sched_group_barrier(0x100, WN + 1, 0);
-      constexpr int MASK_VMEM = 0x010, MASK_DS_READ = 0x100, MASK_MFMA = 0x008;
-      constexpr int NIT = 2 * WM;
-      constexpr int S_PER_IT = (NS + NIT - 1) / NIT;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int fo = foff0 ^ (ks << 6);
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          const int it = ks * WM + i;
-          const int curf = it & 1;
-          int nst = 0;
-#pragma unroll
-          for (int q = 0; q < S_PER_IT; ++q) {
-            const int s = it * S_PER_IT + q;
-            if (s < NS) { stage_one(cur, s, abuf_next, wbuf_next, s < SA ? kt_a : kt_w); ++nst; }
-          }
-          if (i + 1 < WM) af[curf ^ 1] = *(const bf16x8_t*)(ab + (i + 1) * 16 * ROW_BYTES + fo);
-          else if (ks == 0) af[curf ^ 1] = *(const bf16x8_t*)(ab + (fo ^ 64));
-          int nwf = 0;
-          if (ks == 0) {
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-              if (WM - 1 - (j % WM) == i) {
-                wf[1][j] = *(const bf16x8_t*)(wb + j * 16 * ROW_BYTES + (fo ^ 64));
-                ++nwf;
-              }
-          }
-#pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            if constexpr (I8) {
-              typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-              acc[j][i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, wf[ks][j]), __builtin_bit_cast(i32x4_t, af[curf]),
-                                                                                             __builtin_bit_cast(i32x4_t, acc[j][i]), 0, 0, 0));
-            } else {
-              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[curf], acc[j][i], 0, 0, 0);
-            }
-          }
-          const int nreads = ((i + 1 < WM || ks == 0) ? 1 : 0) + nwf;
-          switch (nst) {
-            case 1: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 1, 0); break;
-            case 2: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 2, 0); break;
-            case 3: __builtin_amdgcn_sched_group_barrier(MASK_VMEM, 3, 0); break;
-            default: break;
-          }
-          switch (nreads) {
-            case 1: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 1, 0); break;
-            case 2: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 2, 0); break;
-            case 3: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 3, 0); break;
-            case 4: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 4, 0); break;
-            case 5: __builtin_amdgcn_sched_group_barrier(MASK_DS_READ, 5, 0); break;
-            default: break;
-          }
-          __builtin_amdgcn_sched_group_barrier(MASK_MFMA, WN, 0);
-        }
-      }
-    }
-    // every wave has read its last fragments: the ring may take the next tile.  (The trailing transfers of this tile -- harmless re-loads of its
-    // last k-tile -- and the next tile's are DMA writes of the same wave to the same LDS bytes, which land in issue order.)
-    __builtin_amdgcn_s_barrier();
-
-    staged = false;
-    // ---- epilogue (gemm_tile's), with the next tile's first transfers issued from inside it ---------------------------------------------------
-    ProbView pv;
-    pv.bias = cur.second_prob ? p.g_bias : p.bias;
-    pv.gate = cur.second_prob ? p.g_gate : p.gate;
-    pv.res = cur.second_prob ? p.g_res : p.res;
-    pv.C = cur.second_prob ? p.g_C : p.C;
-    pv.M = cur.M;
-    pv.q8 = cur.second_prob ? p.g_q8 : p.q8; pv.q8_inv = cur.second_prob ? p.g_q8_inv : p.q8_inv; pv.q8_amax = cur.second_prob ? p.g_q8_amax : p.q8_amax;
-    const int nbeg = cur.n0 + wc * 16 * WN + (lane >> 4) * NV;
-    const bool live = nbeg < p.N && p.probe != 1;
-    const bool second = (p.C2 != nullptr) && (cur.n0 >= p.n_split);
-    const int act = second ? p.act2 : p.act;
-    const int mbeg = cur.m0 + wr * 16 * WM + frow;
-    if constexpr (I8) {
-      const __amdgpu_buffer_rsrc_t rsSa = make_rsrc(cur.second_prob ? p.g_a_scale : p.a_scale, (unsigned)pv.M * 4u);
-      const __amdgpu_buffer_rsrc_t rsSw = make_rsrc(cur.second_prob ? p.g_w_scale : p.w_scale, (unsigned)p.N * 4u);
-      float swv[NV];
-#pragma unroll
-      for (int c = 0; c < NV; c += 4) {
-        const f32x4_t w4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsSw, (unsigned)(nbeg + c) * 4u, 0, 0));
-        swv[c] = w4[0]; swv[c + 1] = w4[1]; swv[c + 2] = w4[2]; swv[c + 3] = w4[3];
-      }
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const float sr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsSa, (unsigned)(mbeg + i * 16) * 4u, 0, 0));
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[j][i][r] = (float)(int)as_u32(acc[j][i][r]) * (sr * swv[j * 4 + r]);
-      }
-    }
-    const int mode = act != TD_ACT_NONE ? 0 : (pv.gate ? 1 : (pv.res ? 2 : 0));
-    auto hook = [&]() {
-      __builtin_amdgcn_sched_barrier(0);      // the epilogue's operand loads stay in front of the transfers, its rows behind
-      if (more) {
-        Ctx nxt;
-        setup(t_next, nxt);
-        if (!is_ragged(nxt)) { prologue(nxt); staged = true; }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    epilogue<WM, WN, I8 && WN == 4>(p, pv, acc, mbeg, nbeg, second, act, mode, live, hook);
-    if (!more) return;
-    setup(t_next, cur);
-    t = t_next;
-  }
-}
-
 // XCD-aware numbering: workgroup ids go round-robin over the 8 XCDs; logical index t gives every XCD one CONTIGUOUS run of tiles (its 32 resident
 // tiles then share A / W panels through that XCD's L2), in dispatch order inside the run.
 __device__ __forceinline__ int xcd_contiguous(const int bid, const int nwg) {
@@ -872,33 +624,21 @@ __device__ __forceinline__ int xcd_contiguous(const int bid, const int nwg) {
 // behind the full rounds -- into TAIL sub-tiles of 32 WM / TAIL rows each: workgroups [tail_first_wg, grid) take one sub-tile, so the
 // last round costs 1 / TAIL of a tile time (x the smaller tile's lower efficiency) instead of a whole one.  No split along K, no
 // fix-up pass: every output element is still produced by one workgroup with the full contraction, bit-identical to the unsplit launch.
-template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false, int TAIL = 1, bool PERSIST = false>
+template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false, int TAIL = 1>
 __global__ __launch_bounds__(512, 1) void td_gemm_bf16_nt_kernel(const TdGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses gfx950-only types (__amdgpu_buffer_rsrc_t): the host pass only needs the stub
   static_assert(TAIL == 1 || (WM % TAIL == 0 && !CONV), "tail sub-tiles cut the m extent of the tile");
-  static_assert(!PERSIST || (!CONV && !FP8), "the persistent form exists for the bf16 / int8 main loop");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 32 * WM, BN = 64 * WN;
-  // Workgroup roles.  PERSIST: workgroups [0, pers_wgs) -- one per CU -- walk the tiles of the full rounds, [0, tail_first_wg) in tile units
-  // (gemm_tiles_persistent); the workgroups behind them take one of the remaining tiles each, or one of its TAIL sub-tiles.  Otherwise:
-  // workgroups [0, tail_first_wg) one full tile each, the rest the sub-tiles (TAIL > 1), or simply one tile per workgroup (TAIL == 1).
-  int bid = (int)blockIdx.x, first_rest = TAIL > 1 ? p.tail_first_wg : (int)gridDim.x;
-  if constexpr (PERSIST) {
-    if (bid < p.pers_wgs) {
-      gemm_tiles_persistent<WM, WN, I8>(p, smem, xcd_contiguous(bid, p.pers_wgs), p.pers_wgs, p.tail_first_wg);
-      return;
-    }
-    first_rest = p.pers_wgs;
-  }
   int t, sub = 0;
   bool tail = false;
-  if ((TAIL > 1 || PERSIST) && bid >= first_rest) {
-    const int u = xcd_contiguous(bid - first_rest, (int)gridDim.x - first_rest);
-    t = p.tail_first_wg + u / TAIL;      // (tail_first_wg = the number of tiles in the full rounds = the first remaining tile's logical index)
+  if (TAIL > 1 && (int)blockIdx.x >= p.tail_first_wg) {
+    const int u = xcd_contiguous((int)blockIdx.x - p.tail_first_wg, (int)gridDim.x - p.tail_first_wg);
+    t = p.tail_first_wg + u / TAIL;      // (full tiles: one workgroup each, so the first tail tile's logical index is tail_first_wg)
     sub = u - (u / TAIL) * TAIL;
-    tail = TAIL > 1;
+    tail = true;
   } else {
-    t = xcd_contiguous(bid, first_rest);
+    t = xcd_contiguous((int)blockIdx.x, TAIL > 1 ? p.tail_first_wg : (int)gridDim.x);
   }
   // grouped M ordering of the logical index
   constexpr int GROUP_M = 4;
@@ -955,7 +695,7 @@ int tail_split(long long tiles, int cus) {
   return pick;
 }
 
-template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false, int TAIL = 1, bool PERSIST = false>
+template <int WM, int WN, bool CONV = false, bool FP8 = false, bool I8 = false, int TAIL = 1>
 int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 64 * WN;
   constexpr int LDS = (2 * BM + 3 * BN) * ROW_BYTES;
@@ -967,36 +707,26 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   if (const char* pr = getenv("TD_GEMM_PROBE")) p.probe = atoi(pr);
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   int grid = p.tiles_m * p.tiles_n;
-  if constexpr (TAIL == 1 && !PERSIST && WM == 8 && WN == 4 && !CONV) {      // the 256 x 256 tile of the block Linears
-    const int cus = cu_count();
-    // two or more full rounds of the CUs: one persistent workgroup per CU walks them (bf16 / int8 main loop; TD_GEMM_NO_PERSIST: A/B)
-    const bool pers = !FP8 && !p.out_f32 && grid >= 2 * cus && getenv("TD_GEMM_NO_PERSIST") == nullptr;
-    // ... and see whether the last, partial round is worth cutting into sub-tiles
-    const int s = tail_split(grid, cus);
-    if constexpr (!FP8) {
-      if (pers) return s == 2 ? launch_cfg<WM, WN, CONV, FP8, I8, 2, true>(p0, stream) : s == 4 ? launch_cfg<WM, WN, CONV, FP8, I8, 4, true>(p0, stream)
-                                                                                               : launch_cfg<WM, WN, CONV, FP8, I8, 1, true>(p0, stream);
-    }
+  if constexpr (TAIL == 1 && WM == 8 && WN == 4 && !CONV) {      // the 256 x 256 tile of the block Linears: see whether its last round is worth cutting up
+    const int s = tail_split(grid, cu_count());
     if (s == 2) return launch_cfg<WM, WN, CONV, FP8, I8, 2>(p0, stream);
     if (s == 4) return launch_cfg<WM, WN, CONV, FP8, I8, 4>(p0, stream);
   }
-  if constexpr (TAIL > 1 || PERSIST) {
+  if constexpr (TAIL > 1) {
     const int cus = cu_count();
-    p.tail_first_wg = grid / cus * cus;                        // tiles of the full rounds; a multiple of 8: the XCD numbering of both parts stays aligned
-    const int rest = (grid - p.tail_first_wg) * TAIL;
-    p.pers_wgs = PERSIST ? cus : 0;
-    grid = (PERSIST ? cus : p.tail_first_wg) + rest;
+    p.tail_first_wg = grid / cus * cus;                        // a multiple of 8: the XCD numbering of both parts stays aligned
+    grid = p.tail_first_wg + (grid - p.tail_first_wg) * TAIL;
   }
   // the dynamic-LDS limit is a per-device function attribute: set it once per device (a process may drive several)
   static std::atomic<unsigned long long> attr_done{0ull};
   int dev = 0;
   TD_CHECK_HIP(hipGetDevice(&dev));
   if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL, PERSIST>,
+    TD_CHECK_HIP(hipFuncSetAttribute((const void*)td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL, PERSIST>), dim3(grid), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL>), dim3(grid), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
 }
