@@ -219,6 +219,14 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream);
  * quantisation pass per tensor); 1 = the maxima the PREVIOUS denoise step accumulated for the same tensor and token x 1.25 (clip beyond):
  * the MLP intermediate then leaves the producing GEMM epilogue as int8.  First steps and out-of-order steps use mode 0.  Parent context. */
 int td_flux_set_act_scales(td_flux* f, int mode);
+/* TD_PRECISION_INT8 only: per-channel smoothing of the activations that carry outlier channels (SmoothQuant's balance at alpha = 1/2, factors
+ * rounded to powers of two so that x / s and W s are exact).  mode 1: the FIRST int8 forward after the mode, the precision or a parameter changed
+ * runs on the bf16 path and records per-channel maxima of the LayerNorm outputs and MLP intermediates; from then on those activations are divided by
+ * s[channel] where they are quantised (LayerNorm kernel, int8 GEMM epilogue, quantisation pass) and the consuming weights' input channels are
+ * multiplied by s before their own quantisation.  Per-token int8 then no longer spends its 8 bits on a few channels that run tens of times above
+ * the rest (the failure mode of W8A8 on trained DiTs; tests/test_flux_full_depth_gpu.py grades it on the heavy-tailed fixture).  0 = off (default).
+ * The reference has no such path (it runs bf16): this belongs to BASELINE config 5's 8-bit MFMA path.  Parent context. */
+int td_flux_set_smoothing(td_flux* f, int mode);
 /* Arithmetic of the joint attention in every block: TD_ATTENTION_BF16 (default: the reference graph's) or TD_ATTENTION_FP8 (QK^T and P.V
  * on the e4m3 matrix instruction, td_attention_fp8).  Independent of td_flux_set_precision; meant for the 8-bit modes.  Parent context. */
 enum { TD_ATTENTION_BF16 = 0, TD_ATTENTION_FP8 = 1 };

@@ -168,8 +168,15 @@ def test_full_depth_bf16_28_steps_vs_oracle_fixture(full_model, job):
     assert px < float(os.environ.get("TD_BF16_PIXEL_BAR", "1e-2")), f"bf16 pixels {px:.4f} from the 28-step oracle fixture exceed the 1e-2 bar"
 
 
+# name = <Linear operands>[_smooth][_history][_attn8]: per-channel smoothing (td_flux_set_smoothing), MLP scales from the previous step
+# (td_flux_set_act_scales), joint attention on the e4m3 MFMA (td_flux_set_attention)
 POLICIES = (("bf16", None), ("fp8", None), ("fp8_single", ["single_in", "single_out"]), ("int8", None), ("int8_history", None),
-            ("bf16_attn8", None), ("int8_history_attn8", None))
+            ("bf16_attn8", None), ("int8_history_attn8", None), ("int8_smooth", None), ("int8_smooth_history", None), ("int8_smooth_history_attn8", None))
+
+
+def apply_policy(tr, prec, gemms=None):
+    tr.set_precision(prec.split("_")[0], fp8_gemms=gemms, act_scales="history" if "_history" in prec else "dynamic", smoothing="_smooth" in prec)
+    tr.set_attention("fp8" if prec.endswith("_attn8") else "bf16")
 
 
 def _grade_policies(full_model, job):
@@ -183,8 +190,7 @@ def _grade_policies(full_model, job):
     tr = pipe.transformer
     res = {}
     for prec, gemms in POLICIES:
-        tr.set_precision(prec.split("_")[0], fp8_gemms=gemms, act_scales="history" if "_history" in prec else "dynamic")
-        tr.set_attention("fp8" if prec.endswith("_attn8") else "bf16")
+        apply_policy(tr, prec, gemms)
         out = pipe(prompt_embeds=pe, pooled_prompt_embeds=pool, height=1024, width=1024, num_inference_steps=28, guidance_scale=3.5,
                    latents=lat, output_type="latent").images[0].clone()
         u8 = pipe.vae.decode_packed(out, 128, 128, output_type="np").clone()
@@ -239,13 +245,12 @@ def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
     tr = pipe.transformer
 
     def run(prec):
-        tr.set_precision(prec.split("_")[0], act_scales="history" if "_history" in prec else "dynamic")
-        tr.set_attention("fp8" if prec.endswith("_attn8") else "bf16")
+        apply_policy(tr, prec)
         out = pipe(prompt_embeds=pe, pooled_prompt_embeds=pool, height=1024, width=1024, num_inference_steps=3, guidance_scale=3.5,
                    latents=lat, output_type="latent").images[0].clone()
         torch.cuda.synchronize()
         return out
-    for prec in ("bf16", "int8", "int8_history", "int8_history_attn8"):
+    for prec in ("bf16", "int8", "int8_history", "int8_history_attn8", "int8_smooth_history_attn8"):
         monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
         base = run(prec)
         monkeypatch.delenv("TD_GEMM_NO_TAIL")

@@ -88,14 +88,20 @@ __device__ __forceinline__ void to_e4m3_32(const float (&x)[32], const float mul
   }
 }
 
-__device__ __forceinline__ void load_row32(const bf16_t* p, bool live, float (&x)[32]) {
+// A thread's 32 bf16 of a head row: fetched as four 16-byte loads (raw), unpacked where they are used -- the pack kernel issues the q, k and v
+// fetches of a thread together, ahead of the first use, so the three sections do not each pay an HBM round trip of their own
+__device__ __forceinline__ void fetch_row32(const bf16_t* p, bool live, u32x4_t (&raw)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    u32x4_t v = {0u, 0u, 0u, 0u};
-    if (live) v = *(const u32x4_t*)(p + 8 * i);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[8 * i + 2 * j] = bf_lo(v[j]); x[8 * i + 2 * j + 1] = bf_hi(v[j]); }
+    raw[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if (live) raw[i] = *(const u32x4_t*)(p + 8 * i);
   }
+}
+__device__ __forceinline__ void unpack_row32(const u32x4_t (&raw)[4], float (&x)[32]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[8 * i + 2 * j] = bf_lo(raw[i][j]); x[8 * i + 2 * j + 1] = bf_hi(raw[i][j]); }
 }
 
 // QK-RMSNorm + rotary embedding of td_qk_norm_rope_kernel on this thread's 32 elements of a head row (quarter qt of the row; the four
@@ -145,7 +151,8 @@ __device__ __forceinline__ void norm_rope_32(float (&x)[32], const bf16_t* w, co
 }  // namespace
 
 // One workgroup per (64-token tile, head): thread (row = tid / 4, quarter = tid % 4) owns 32 of a token's 128 head dims.
-__global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParams p, char* __restrict__ ws, const F8Layout lay, const float qmul, const int nt) {
+// `probe` (TD_PACK_PROBE, timing experiments only -- the attention then runs on stale operands): bit 0 skips the v section, bit 1 k, bit 2 q.
+__global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParams p, char* __restrict__ ws, const F8Layout lay, const float qmul, const int nt, const int probe) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) uint8_t vimg[TILE8];
   __shared__ float wmax[4];
@@ -170,9 +177,15 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
     }
   }
   const bool partB = tok >= p.rope_split;
+  const bool live = tok < p.Skv;
+  // all three rows of this thread are requested here (probe builds skip a section's fetch with the section)
+  u32x4_t rq[4], rk[4], rv[4];
+  fetch_row32(p.Q + (size_t)min(tok, p.Sq - 1) * p.ldq + head * D + qt * 32, tok < p.Sq && !(probe & 4), rq);
+  fetch_row32(p.K + (size_t)(live ? tok : 0) * p.ldkv + head * D + qt * 32, live && t < nt && !(probe & 2), rk);
+  fetch_row32(p.V + (size_t)(live ? tok : 0) * p.ldkv + head * D + qt * 32, live && t < nt && !(probe & 1), rv);
 
-  if (tok < p.Sq) {      // ---- q: row-major, scale per (token, head)
-    load_row32(p.Q + (size_t)tok * p.ldq + head * D + qt * 32, true, x);
+  if (tok < p.Sq && !(probe & 4)) {      // ---- q: row-major, scale per (token, head)
+    unpack_row32(rq, x);
     if (rope) norm_rope_32(x, partB ? p.rope_wqB : p.rope_wqA, qt, p.rope_eps, cs, sn, p.rope_q_premul);
     float am = 0.f;
 #pragma unroll
@@ -192,10 +205,9 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
     }
   }
   if (t >= nt) return;   // (Sq > Skv: the remaining tiles carry queries only)
-  const bool live = tok < p.Skv;
   const size_t tile = (size_t)head * nt + t;
-  {                      // ---- k: the swizzled LDS image of the tile, scale per (key, head); rows past Skv are zero
-    load_row32(p.K + (size_t)(live ? tok : 0) * p.ldkv + head * D + qt * 32, live, x);
+  if (!(probe & 2)) {    // ---- k: the swizzled LDS image of the tile, scale per (key, head); rows past Skv are zero
+    unpack_row32(rk, x);
     if (rope && live) norm_rope_32(x, partB ? p.rope_wkB : p.rope_wkA, qt, p.rope_eps, cs, sn, 1.0f);      // (live is uniform over a row's four threads)
     float am = 0.f;
 #pragma unroll
@@ -210,8 +222,8 @@ __global__ __launch_bounds__(256) void td_attn_fp8_pack_kernel(const TdAttnParam
     *(u32x4_t*)(dst + (((2 * qt + 1) ^ sw) << 4)) = u32x4_t{w[4], w[5], w[6], w[7]};
     if (qt == 0) ((uint8_t*)ws + lay.ks)[tile * KV_TILE + (row & 31) * 2 + (row >> 5)] = (uint8_t)sb;   // lane l31 reads its two k-blocks' bytes as one u16
   }
-  {                      // ---- v: transposed through LDS, one scale per (tile, head), keys in the accumulator's order
-    load_row32(p.V + (size_t)(live ? tok : 0) * p.ldkv + head * D + qt * 32, live, x);
+  if (!(probe & 1)) {    // ---- v: transposed through LDS, one scale per (tile, head), keys in the accumulator's order
+    unpack_row32(rv, x);
     float am = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) am = fmaxf(am, fabsf(x[i]));
@@ -649,7 +661,8 @@ int td_attn_fp8_launch(const TdAttnParams& p, hipStream_t stream) {
   const bool lin = !(p.variant & 0x2000);          // variant bit 0x2000 (A/B, tests): probabilities by exp2 + e4m3 conversion instead of the integer form
   const float qmul = (p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f) * (lin ? 8.0f : 1.0f);
   const int nt_pack = max(nt, (p.Sq + KV_TILE - 1) / KV_TILE);
-  hipLaunchKernelGGL(td_attn_fp8_pack_kernel, dim3(nt_pack, p.Hq), dim3(256), 0, stream, p, (char*)p.f8_ws, lay, qmul, nt);
+  const char* pack_probe = getenv("TD_PACK_PROBE");
+  hipLaunchKernelGGL(td_attn_fp8_pack_kernel, dim3(nt_pack, p.Hq), dim3(256), 0, stream, p, (char*)p.f8_ws, lay, qmul, nt, pack_probe ? atoi(pack_probe) : 0);
   TD_CHECK_LAUNCH();
   const int G = min(cus * (8 / NW), n_items);       // a range is never shorter than an item: every item is split over at most two workgroups
   constexpr int lds = 8 * TILE8 + 16;

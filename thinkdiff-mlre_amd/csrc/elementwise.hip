@@ -106,9 +106,12 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
       for (int i = 0; i < 8; ++i) y[i] = rbf(rbf(y[i] * rbf(1.0f + sc[i])) + sh[i]);
     }
     if (p.q) {   // keep the bf16-rounded row in registers for the quantisation pass
+      float sm[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      const bf16_t* smooth = partB ? p.smoothB : p.smoothA;      // int8 smoothing: 1 / s per channel (a power of two: exact on a bf16 value)
+      if (smooth) unpack8(*(const u32x4_t*)(smooth + col), sm);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        v[c][i] = rbf(y[i]);
+        v[c][i] = rbf(y[i]) * sm[i];
         amax = fmaxf(amax, fabsf(v[c][i]));
       }
     } else {
@@ -121,8 +124,21 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
     const float inv = 1.0f / s;
     if (lane == 0) p.q_scale[row] = s;
     uint8_t* qr = p.q + (size_t)row * p.ldq;
+    const int* ext = partB ? p.extB : p.extA;
+    __shared__ __attribute__((aligned(8))) uint8_t qrow[4][NCH * 512];      // the quantised row of each of the block's 4 waves (replicated channels only)
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) *(u32x2_t*)(qr + c * 512 + lane * 8) = pack8_q(v[c], inv, p.q_int8 != 0);
+    for (int c = 0; c < NCH; ++c) {
+      const u32x2_t b = pack8_q(v[c], inv, p.q_int8 != 0);
+      *(u32x2_t*)(qr + c * 512 + lane * 8) = b;
+      if (ext) *(u32x2_t*)(&qrow[threadIdx.x >> 6][c * 512 + lane * 8]) = b;
+    }
+    if (ext) {      // (wave-uniform; a wave reads only what it wrote itself: LDS operations of a wave complete in order)
+      for (int e = lane * 2; e < p.ext_n; e += 128) {
+        const int s0 = ext[e], s1 = ext[e + 1];
+        const unsigned b0 = s0 >= 0 ? qrow[threadIdx.x >> 6][s0] : 0u, b1 = s1 >= 0 ? qrow[threadIdx.x >> 6][s1] : 0u;
+        *(unsigned short*)(qr + NCH * 512 + e) = (unsigned short)(b0 | (b1 << 8));
+      }
+    }
   }
 }
 
@@ -132,6 +148,8 @@ int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.ldx % 8 == 0 && p.ldy % 8 == 0, "td_norm_rows: row strides must be multiples of 8");
   TD_CHECK_ARG((p.scaleA == nullptr) == (p.shiftA == nullptr), "td_norm_rows: shift and scale come together");
   if (p.q) TD_CHECK_ARG(p.q_scale && p.ldq % 8 == 0 && (uintptr_t)p.q % 8 == 0, "td_norm_rows: fp8 output needs a scale array and 8-byte aligned rows");
+  if (p.extA || p.extB) TD_CHECK_ARG(p.q && p.q_int8 && p.extA && p.extB && p.ext_n > 0 && p.ext_n % 2 == 0 && p.ldq >= p.D + p.ext_n,
+                                     "td_norm_rows: replicated channels need the int8 output form, both tables and rows of D + ext_n bytes");
   TD_GRID_1D(nblk, (long long)((p.rows + 3) / 4) * 256, 256, "td_norm_rows");
   const dim3 grid(nblk), block(256);
   switch (p.D / 512) {
@@ -672,7 +690,16 @@ int td_vision_rope_table_launch(const int* pos, int S, int hd, float theta, floa
 
 
 // ---- per-row dynamic fp8 (OCP e4m3) quantisation: weights at load time (per output channel), activations per token ----
-__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, int int8, unsigned* amax_out) {
+// col_mul (may be null): fp32 [K], every element is multiplied by its column's factor first -- the smoothing factors of the int8 mode (powers of
+// two: s on a weight's input channels, 1 / s on the activation that meets it; td_flux_set_smoothing)
+__device__ __forceinline__ void mul8_cols(float (&v)[8], const float* col_mul, int c) {
+  if (col_mul) {
+    const f32x4_t a = *(const f32x4_t*)(col_mul + c), b = *(const f32x4_t*)(col_mul + c + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] *= a[i]; v[4 + i] *= b[i]; }
+  }
+}
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, int int8, unsigned* amax_out, const float* col_mul) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -681,6 +708,7 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x,
   for (int c = lane * 8; c < K; c += 512) {
     float v[8];
     unpack8(*(const u32x4_t*)(xr + c), v);
+    mul8_cols(v, col_mul, c);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
   }
@@ -692,13 +720,14 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_kernel(const bf16_t* x,
   for (int c = lane * 8; c < K; c += 512) {
     float v[8];
     unpack8(*(const u32x4_t*)(xr + c), v);
+    mul8_cols(v, col_mul, c);
     *(u32x2_t*)(qr + c) = pack8_q(v, inv, int8 != 0);
   }
 }
 
 // the same with the row held in registers between the amax pass and the conversion (K = NCH * 512 <= 16384): one read of x
 template <int NCH>
-__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int int8, unsigned* amax_out) {
+__global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int int8, unsigned* amax_out) {      // (col_mul launches take the generic kernel)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -724,15 +753,16 @@ __global__ __launch_bounds__(256) void td_quant_rows_fp8_reg_kernel(const bf16_t
   }
 }
 
-int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8, unsigned* amax_out) {
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8, unsigned* amax_out, const float* col_mul) {
   TD_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0, "td_quant_rows_fp8: bad arguments");
+  TD_CHECK_ARG(!col_mul || ((uintptr_t)col_mul) % 16 == 0, "td_quant_rows_fp8: the column factors must be 16-byte aligned");
   TD_GRID_1D(nblk, (long long)((rows + 3) / 4) * 256, 256, "td_quant_rows_fp8");
   const dim3 grid(nblk), block(256);
-  switch (K % 512 == 0 ? K / 512 : 0) {
+  switch (K % 512 == 0 && !col_mul ? K / 512 : 0) {
 #define TD_CASE(n) case n: hipLaunchKernelGGL(td_quant_rows_fp8_reg_kernel<n>, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, int8, amax_out); break;
     TD_CASE(1) TD_CASE(2) TD_CASE(4) TD_CASE(6) TD_CASE(8) TD_CASE(24) TD_CASE(30)
 #undef TD_CASE
-    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K, int8, amax_out);
+    default: hipLaunchKernelGGL(td_quant_rows_fp8_kernel, grid, block, 0, stream, x, ldx, q, ldq, scale, rows, K, int8, amax_out, col_mul);
   }
   TD_CHECK_LAUNCH();
   return 0;
@@ -757,6 +787,70 @@ int td_q8_scales_from_amax_launch(unsigned* amax, float* scale, float* inv, long
   TD_CHECK_ARG(amax && scale && inv && n > 0 && margin >= 1.0f, "td_q8_scales_from_amax: bad arguments");
   TD_GRID_1D(nblk, n, 256, "td_q8_scales_from_amax");
   hipLaunchKernelGGL(td_q8_scales_from_amax_kernel, dim3(nblk), dim3(256), 0, stream, amax, scale, inv, n, margin);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- int8 smoothing (td_flux_set_smoothing): per-channel maxima and the factors made from them ---------------------------------------------------
+// amax[c] = max(amax[c], max_r |x[r, c]|) over rows [0, rows) (atomic max on the float bits: all values are >= 0).  One thread owns 8 columns of a
+// 64-row strip.  Used on activations during the calibration forward and on weights (columns = input channels) when the factors are made.
+__global__ __launch_bounds__(256) void td_col_amax_kernel(const bf16_t* x, int ldx, int rows, int K, unsigned* amax) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= K) return;
+  const int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + (size_t)r * ldx + c), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(v[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (m[i] > 0.f) atomicMax(amax + c + i, as_u32(m[i]));
+}
+int td_col_amax_launch(const bf16_t* x, int ldx, int rows, int K, unsigned* amax, hipStream_t stream) {
+  TD_CHECK_ARG(x && amax && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x) % 16 == 0, "td_col_amax: bad arguments");
+  const dim3 grid((K / 8 + 255) / 256, (rows + 63) / 64);
+  TD_CHECK_ARG(grid.y < 65536, "td_col_amax: %d rows exceed the grid", rows);
+  hipLaunchKernelGGL(td_col_amax_kernel, grid, dim3(256), 0, stream, x, ldx, rows, K, amax);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+// SmoothQuant's balance with alpha = 1/2, rounded to a power of two: s[c] = 2^rint(log2(sqrt(amax_x[c] / amax_w[c]))) in [2^-8, 2^8] -- the
+// activation channel is divided by s, the weight's input channel multiplied by it; both are exact on bf16 values, so the product is unchanged and
+// only where the quantisation steps fall moves.  A channel never seen (either maximum 0) keeps s = 1.
+__global__ void td_smooth_factors_kernel(const unsigned* ax, const unsigned* aw, int n, float* s, float* inv, bf16_t* inv16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = as_f32(ax[i]), w = as_f32(aw[i]);
+  float e = 0.f;
+  if (a > 0.f && w > 0.f) e = fminf(fmaxf(rintf(0.5f * (log2f(a) - log2f(w))), -8.f), 8.f);
+  const float sv = exp2f(e);
+  s[i] = sv;
+  inv[i] = 1.0f / sv;
+  inv16[i] = f2bf(1.0f / sv);
+}
+int td_smooth_factors_launch(const unsigned* ax, const unsigned* aw, int n, float* s, float* inv, bf16_t* inv16, hipStream_t stream) {
+  TD_CHECK_ARG(ax && aw && s && inv && inv16 && n > 0, "td_smooth_factors: bad arguments");
+  hipLaunchKernelGGL(td_smooth_factors_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ax, aw, n, s, inv, inv16);
+  TD_CHECK_LAUNCH();
+  return 0;
+}
+
+// q[r, K + e] = q[r, ext[e]] (0 where ext[e] < 0): the replicated input channels of an int8 weight (TdNormParams::ext)
+__global__ void td_ext_cols_kernel(uint8_t* q, int ld, int rows, int K, const int* ext, int ext_n) {
+  const int r = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  uint8_t* qr = q + (size_t)r * ld;
+  for (int e = lane; e < ext_n; e += 64) {
+    const int src = ext[e];
+    qr[K + e] = src >= 0 ? qr[src] : (uint8_t)0;
+  }
+}
+int td_ext_cols_launch(uint8_t* q, int ld, int rows, int K, const int* ext, int ext_n, hipStream_t stream) {
+  TD_CHECK_ARG(q && ext && rows > 0 && K > 0 && ext_n > 0 && ld >= K + ext_n, "td_ext_cols: bad arguments");
+  hipLaunchKernelGGL(td_ext_cols_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, q, ld, rows, K, ext, ext_n);
   TD_CHECK_LAUNCH();
   return 0;
 }

@@ -20,6 +20,8 @@
 //    (reads 6.5 GB of modulation weights once per image instead of once per step);
 //  * bias / GELU / gate*x + residual are GEMM epilogues; LayerNorm+modulate and QK-RMSNorm+RoPE are
 //    single-pass row kernels.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -54,6 +56,9 @@ struct Fp8Mat {
   float* s = nullptr;
 };
 struct DoubleW8 { Fp8Mat qkv_img, qkv_ctx, out_img, out_ctx, ff1_img, ff1_ctx, ff2_img, ff2_ctx; };
+// int8 smoothing: the Linears fed by a LayerNorm output (q|k|v, ff.net.0, proj_mlp | q|k|v of the single blocks) may carry up to SM_EXT replicated
+// input channels behind their D real ones (one more k-tile); their int8 weights and the quantised LayerNorm rows are allocated for D + SM_EXT
+constexpr int SM_EXT = 128;
 struct SingleW8 { Fp8Mat w1, w2; };
 
 }  // namespace
@@ -110,6 +115,19 @@ struct td_flux {
   unsigned* hs_amax = nullptr;
   int hs_cap = 0;                           // tokens per tensor in the three arrays
   int hs_step = -1, hs_T = 0, hs_S = 0;     // the step (and token layout) whose maxima hs_amax holds
+  // int8 smoothing (td_flux_set_smoothing; parent context).  Per input channel of the Linears that read a LayerNorm output or an MLP intermediate,
+  // a power-of-two factor s: the activation channel is divided by s where it is quantised, the weight's input channel multiplied by s before ITS
+  // quantisation.  The factors come from ONE calibration forward (the first forward after the mode / the weights / the precision changed, run on the
+  // bf16 path with per-channel maxima collected along the way).  Layout of every vector below, in channels: double block i at i (4 D + 2 M):
+  // qkv_img[D] qkv_ctx[D] ff1_img[D] ff1_ctx[D] ff2_img[M] ff2_ctx[M]; single block i at L (4 D + 2 M) + i (2 D + M): w1[D] w2[D + M] (the
+  // attention half of w2's operand is never smoothed: its maxima stay 0 and its factors 1).
+  int smooth_mode = 0;
+  bool smooth_ready = false;
+  int* sm_ext = nullptr;                            // replicated channels of the LayerNorm-fed Linears: [4 L + Ls tensors][SM_EXT] source channel or -1
+  int64_t smooth_n = 0;
+  unsigned *sm_ax = nullptr, *sm_aw = nullptr;      // channel maxima of the activations / of the weights' input channels (float bits)
+  float *sm_s = nullptr, *sm_inv = nullptr;         // s, 1 / s
+  bf16_t* sm_inv16 = nullptr;                       // 1 / s as bf16 (the LayerNorm and GEMM epilogue kernels read it beside their bf16 operands)
   // a forked context (td_flux_fork) shares the parent's weights (bf16 arena, fp8 arena, precision) and owns its
   // workspace, conditioning and schedule: several images in flight on separate streams fill each other's kernel tails
   td_flux* parent = nullptr;
@@ -187,7 +205,7 @@ int gemm2(td_flux* f, hipStream_t s, const bf16_t* A0, const bf16_t* W0, const b
 
 // fp8 forms of gemm / gemm2: A is e4m3 rows + per-row scales, W an Fp8Mat
 // int8 output of the activated result under scales fixed in advance (TdGemmParams::q8)
-struct Q8Out { uint8_t* q = nullptr; int ld = 0; const float* inv = nullptr; unsigned* amax = nullptr; };
+struct Q8Out { uint8_t* q = nullptr; int ld = 0; const float* inv = nullptr; unsigned* amax = nullptr; const bf16_t* smooth = nullptr; };
 
 int gemm8(td_flux* f, hipStream_t s, const uint8_t* A, int lda, const float* a_scale, const Fp8Mat& W, const bf16_t* b, bf16_t* C, int ldc,
           int M, int N, int K, int act = TD_ACT_NONE, const bf16_t* gate = nullptr, const bf16_t* res = nullptr, int ldr = 0,
@@ -198,7 +216,7 @@ int gemm8(td_flux* f, hipStream_t s, const uint8_t* A, int lda, const float* a_s
   p.A = (const bf16_t*)A; p.lda = lda; p.a_scale = a_scale; p.W = (const bf16_t*)W.q; p.w_scale = W.s;
   p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.n_split = n_split;
-  if (q8) { p.q8 = q8->q; p.ldq8 = q8->ld; p.q8_inv = q8->inv; p.q8_amax = q8->amax; }
+  if (q8) { p.q8 = q8->q; p.ldq8 = q8->ld; p.q8_inv = q8->inv; p.q8_amax = q8->amax; p.q8_smooth = q8->smooth; }
   const int cfg = td_gemm_config_id(M, N, K / 2);
   TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * M * N * K);
   return td_gemm_launch(p, s);
@@ -209,8 +227,8 @@ int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, cons
             const Q8Out* q8_0 = nullptr, const Q8Out* q8_1 = nullptr) {
   TdGemmParams p;
   if (q8_0 && q8_1) {
-    p.q8 = q8_0->q; p.ldq8 = q8_0->ld; p.q8_inv = q8_0->inv; p.q8_amax = q8_0->amax;
-    p.g_q8 = q8_1->q; p.g_q8_inv = q8_1->inv; p.g_q8_amax = q8_1->amax;
+    p.q8 = q8_0->q; p.ldq8 = q8_0->ld; p.q8_inv = q8_0->inv; p.q8_amax = q8_0->amax; p.q8_smooth = q8_0->smooth;
+    p.g_q8 = q8_1->q; p.g_q8_inv = q8_1->inv; p.g_q8_amax = q8_1->amax; p.g_q8_smooth = q8_1->smooth;
   }
   const td_flux* root8 = f->parent ? f->parent : f;
   p.fp8 = root8->precision == TD_PRECISION_FP8_E4M3; p.i8 = root8->precision == TD_PRECISION_INT8;
@@ -223,10 +241,11 @@ int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, cons
   TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * (M0 + M1) * N * K);
   return td_gemm_launch(p, s);
 }
-// per-token quantisation of a bf16 activation matrix into f->aq / f->as_
-int quant_act(td_flux* f, hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned* amax_out = nullptr) {
+// per-token quantisation of a bf16 activation matrix into f->aq / f->as_ (rows row0 .. row0 + rows - 1 of both); col_mul: int8 smoothing factors (1 / s)
+int quant_act(td_flux* f, hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned* amax_out = nullptr, const float* col_mul = nullptr, int row0 = 0) {
   TraceScope ts(f, s, TD_TRACE_NORM, 0.0);
-  return td_quant_rows_fp8_launch(x, ldx, f->aq, K, f->as_, rows, K, s, (f->parent ? f->parent : f)->precision == TD_PRECISION_INT8, amax_out);
+  return td_quant_rows_fp8_launch(x + (size_t)row0 * ldx, ldx, f->aq + (size_t)row0 * K, K, f->as_ + row0, rows, K, s,
+                                  (f->parent ? f->parent : f)->precision == TD_PRECISION_INT8, amax_out ? amax_out + row0 : nullptr, col_mul);
 }
 
 int norm_rows(td_flux* f, hipStream_t s, const TdNormParams& p) {
@@ -294,7 +313,7 @@ int alloc_workspace(td_flux* f) {
       {(void**)&f->temb, n * D * 2}, {(void**)&f->st, n * D * 2}, {(void**)&f->mods, n * (int64_t)f->NMOD * 2},
       {(void**)&f->cosT, S * 128 * 4}, {(void**)&f->sinT, S * 128 * 4}, {(void**)&f->ids, S * 3 * 4},
       {(void**)&f->tvals, (n + 1) * 4},
-      {(void**)&f->xq, S * D}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
+      {(void**)&f->xq, S * (D + SM_EXT)}, {(void**)&f->aq, S * (D + M)}, {(void**)&f->xs, S * 4}, {(void**)&f->as_, S * 4},   // fp8 mode activations
       {(void**)&f->attn_ws, (int64_t)td_attn_streamk_ws_bytes()},
       {(void**)&f->attn8_ws, (int64_t)td_attn_fp8_ws_bytes((int)S, (int)S, cfg->num_heads)},
       {(void**)&f->href[0], (int64_t)(cfg->num_layers + cfg->num_single_layers) * cfg->num_heads * S * 4},
@@ -443,6 +462,8 @@ void td_flux_destroy(td_flux* f) {
   if (!f->parent) {
     (void)hipFree(f->arena);
     if (f->arena8) (void)hipFree(f->arena8);
+    if (f->sm_ax) (void)hipFree(f->sm_ax);      // one allocation: ax | aw | s | inv | inv16
+    if (f->sm_ext) (void)hipFree(f->sm_ext);
   }
   (void)hipFree(f->ws);
   delete f;
@@ -521,6 +542,7 @@ int td_flux_load_param(td_flux* f, const char* name, const void* src, int64_t co
   TD_CHECK_ARG(f && name && src, "td_flux_load_param: null argument");
   (f->parent ? f->parent : f)->bounds_dirty = true;
   ++(f->parent ? f->parent : f)->hist_epoch;
+  (f->parent ? f->parent : f)->smooth_ready = false;
   auto it = f->index.find(name);
   TD_CHECK_ARG(it != f->index.end(), "td_flux_load_param: unknown parameter '%s'", name);
   const Slot& s = f->slots[it->second];
@@ -551,6 +573,162 @@ int td_flux_set_act_scales(td_flux* f, int mode) {
   return TD_OK;
 }
 
+// TD_PRECISION_INT8 only: per-channel smoothing of the activations that carry outlier channels (SmoothQuant's balance, alpha = 1/2, factors rounded
+// to powers of two).  Per-token symmetric int8 gives every channel of a row the step max|row| / 127: a trained DiT's few residual-stream /
+// MLP channels that run tens of times above the rest then leave the rest 2-3 bits.  With mode 1 the FIRST int8 forward after the mode, the
+// precision or a parameter changed runs on the bf16 path and records, per input channel of the Linears fed by a LayerNorm output (q|k|v, ff.net.0,
+// proj_mlp) or by an MLP intermediate (ff.net.2, proj_out's MLP half), the largest activation; s = 2^rint(log2 sqrt(max|x_c| / max|W[:, c]|)) then
+// divides that activation channel (inside the LayerNorm kernel, the producing GEMM's int8 epilogue or the quantisation pass) and multiplies the
+// weight's input channel before the weight is quantised again.  Powers of two: x / s and W s are exact, the product is the unsmoothed one, only
+// the quantisation steps move.  0 (default) = off.  Parent context.
+int td_flux_set_smoothing(td_flux* f, int mode) {
+  TD_CHECK_ARG(f && !f->parent && (mode == 0 || mode == 1), "td_flux_set_smoothing: parent context, mode 0 or 1");
+  if (mode == 1 && !f->sm_ax) {
+    const int64_t D = f->D, M = f->M;
+    const int64_t n = (int64_t)f->cfg.num_layers * (4 * D + 2 * M) + (int64_t)f->cfg.num_single_layers * (2 * D + M);
+    char* base = nullptr;
+    TD_CHECK_HIP(hipMalloc((void**)&base, (size_t)n * (4 + 4 + 4 + 4 + 2)));
+    f->smooth_n = n;
+    f->sm_ax = (unsigned*)base; f->sm_aw = f->sm_ax + n; f->sm_s = (float*)(f->sm_aw + n); f->sm_inv = f->sm_s + n; f->sm_inv16 = (bf16_t*)(f->sm_inv + n);
+    TD_CHECK_HIP(hipMalloc((void**)&f->sm_ext, (size_t)(4 * f->cfg.num_layers + f->cfg.num_single_layers) * SM_EXT * sizeof(int)));
+  }
+  if (mode != f->smooth_mode) {
+    ++f->hist_epoch;
+    f->smooth_ready = false;
+    // leaving the mode: the int8 weights must lose their column factors -- quantise them again from the bf16 arena
+    if (mode == 0 && f->smooth_mode == 1 && f->precision == TD_PRECISION_INT8 && f->arena8) { f->smooth_mode = 0; return td_flux_set_precision(f, TD_PRECISION_INT8, nullptr); }
+  }
+  f->smooth_mode = mode;
+  return TD_OK;
+}
+
+}  // extern "C"
+
+namespace {
+inline int64_t sm_dbl(const td_flux* r, int i) { return (int64_t)i * (4 * (int64_t)r->D + 2 * (int64_t)r->M); }
+inline int64_t sm_sgl(const td_flux* r, int i) { return (int64_t)r->cfg.num_layers * (4 * (int64_t)r->D + 2 * (int64_t)r->M) + (int64_t)i * (2 * (int64_t)r->D + r->M); }
+
+// Factors of one Linear's input channels from the maxima the calibration forward saw (ax) and the weight's column maxima (aw), on the host.
+// A channel is an outlier when its maximum is more than 4 x the median channel's; it is brought down to ~2 x the median by a power of two t:
+//   * as far as the weight's own column is SMALLER than the median column (a trained MLP pairs an outlier intermediate channel with small
+//     weights), multiplicatively: activation / m, weight column x m -- free, the column only returns to normal size;
+//   * what is left, r = t / m, by REPLICATION where the operand has room for it (ext != null: the LayerNorm-fed Linears, SM_EXT spare channels
+//     per tensor, largest outliers first): activation / r, present r times, weight column untouched -- the contraction sums r x (x / r) w;
+//   * the rest (no room, or an MLP-fed Linear whose weight column is not small) by SmoothQuant's even split: activation / sqrt, weight x sqrt.
+// Every other channel keeps factor 1: on a checkpoint without outlier channels the smoothed form IS the plain one.
+void smooth_plan(const float* ax, const float* aw, int K, float* s_w, float* inv_a, int* ext) {
+  std::vector<float> v;
+  for (int c = 0; c < K; ++c) if (ax[c] > 0.f) v.push_back(ax[c]);
+  for (int c = 0; c < K; ++c) { s_w[c] = 1.f; inv_a[c] = 1.f; }
+  if (ext) for (int e = 0; e < SM_EXT; ++e) ext[e] = -1;
+  if (v.size() < 16) return;
+  std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+  const float med = v[v.size() / 2];
+  std::vector<float> wv;
+  for (int c = 0; c < K; ++c) if (aw[c] > 0.f) wv.push_back(aw[c]);
+  float wmed = 0.f;
+  if (!wv.empty()) { std::nth_element(wv.begin(), wv.begin() + wv.size() / 2, wv.end()); wmed = wv[wv.size() / 2]; }
+  auto pow2floor = [](float x) { return x >= 1.f ? std::exp2(std::floor(std::log2(x))) : 1.f; };
+  struct Out { int c; float t, m, r; };
+  std::vector<Out> outs;
+  for (int c = 0; c < K; ++c) {
+    if (!(ax[c] > 4.f * med)) continue;
+    const float t = std::min(pow2floor(ax[c] / (2.f * med)), 256.f);
+    const float m = (aw[c] > 0.f && wmed > 0.f) ? std::min(t, pow2floor(wmed / aw[c])) : 1.f;
+    outs.push_back({c, t, m, t / m});
+  }
+  std::sort(outs.begin(), outs.end(), [](const Out& a, const Out& b) { return a.r > b.r; });
+  int room = ext ? SM_EXT : 0, e = 0;
+  for (Out& o : outs) {
+    float r = o.r;
+    while (r > 1.f && (int)r - 1 > room) r *= 0.5f;      // as many copies as still fit
+    const float rest = o.r / r;                            // what replication could not take: split evenly (power of two nearest the square root)
+    const float half = rest > 1.f ? std::exp2(std::rint(0.5f * std::log2(rest))) : 1.f;
+    for (int k = 0; k < (int)r - 1; ++k) ext[e++] = o.c;
+    room -= (int)r - 1;
+    s_w[o.c] = o.m * half;
+    inv_a[o.c] = 1.f / (o.m * r * half);
+  }
+}
+
+// End of the calibration forward (stream s): the weights' input-channel maxima, the plan of every smoothed Linear (host), the int8 weights again.
+int finish_smoothing(td_flux* root, hipStream_t s) {
+  const int64_t D = root->D, M = root->M, n = root->smooth_n;
+  const int L = root->cfg.num_layers, Ls = root->cfg.num_single_layers;
+  TD_CHECK_HIP(hipMemsetAsync(root->sm_aw, 0, (size_t)n * 4, s));
+  for (int i = 0; i < L; ++i) {
+    const DoubleW& w = root->dbl[i];
+    unsigned* a = root->sm_aw + sm_dbl(root, i);
+    TD_TRY(td_col_amax_launch(w.qkv_img_w, (int)D, (int)(3 * D), (int)D, a, s));
+    TD_TRY(td_col_amax_launch(w.qkv_ctx_w, (int)D, (int)(3 * D), (int)D, a + D, s));
+    TD_TRY(td_col_amax_launch(w.ff1_img_w, (int)D, (int)M, (int)D, a + 2 * D, s));
+    TD_TRY(td_col_amax_launch(w.ff1_ctx_w, (int)D, (int)M, (int)D, a + 3 * D, s));
+    TD_TRY(td_col_amax_launch(w.ff2_img_w, (int)M, (int)D, (int)M, a + 4 * D, s));
+    TD_TRY(td_col_amax_launch(w.ff2_ctx_w, (int)M, (int)D, (int)M, a + 4 * D + M, s));
+  }
+  for (int i = 0; i < Ls; ++i) {
+    unsigned* a = root->sm_aw + sm_sgl(root, i);
+    TD_TRY(td_col_amax_launch(root->sgl[i].w1, (int)D, (int)(3 * D + M), (int)D, a, s));
+    TD_TRY(td_col_amax_launch(root->sgl[i].w2, (int)(D + M), (int)D, (int)(D + M), a + D, s));
+  }
+  std::vector<float> ax(n), aw(n), sw(n), inv(n);
+  std::vector<bf16_t> inv16(n);
+  std::vector<int> ext((size_t)(4 * L + Ls) * SM_EXT, -1);
+  TD_CHECK_HIP(hipMemcpyAsync(ax.data(), root->sm_ax, (size_t)n * 4, hipMemcpyDeviceToHost, s));      // (float bits of non-negative values)
+  TD_CHECK_HIP(hipMemcpyAsync(aw.data(), root->sm_aw, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  TD_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < L; ++i) {
+    const int64_t o = sm_dbl(root, i);
+    for (int k = 0; k < 4; ++k)      // qkv_img, qkv_ctx, ff1_img, ff1_ctx: LayerNorm-fed, replication available
+      smooth_plan(&ax[o + k * D], &aw[o + k * D], (int)D, &sw[o + k * D], &inv[o + k * D], &ext[(size_t)(4 * i + k) * SM_EXT]);
+    smooth_plan(&ax[o + 4 * D], &aw[o + 4 * D], (int)M, &sw[o + 4 * D], &inv[o + 4 * D], nullptr);
+    smooth_plan(&ax[o + 4 * D + M], &aw[o + 4 * D + M], (int)M, &sw[o + 4 * D + M], &inv[o + 4 * D + M], nullptr);
+  }
+  for (int i = 0; i < Ls; ++i) {
+    const int64_t o = sm_sgl(root, i);
+    smooth_plan(&ax[o], &aw[o], (int)D, &sw[o], &inv[o], &ext[(size_t)(4 * L + i) * SM_EXT]);
+    for (int64_t c = 0; c < D; ++c) { sw[o + D + c] = 1.f; inv[o + D + c] = 1.f; }      // w2's attention half: never smoothed
+    smooth_plan(&ax[o + 2 * D], &aw[o + 2 * D], (int)M, &sw[o + 2 * D], &inv[o + 2 * D], nullptr);
+  }
+  for (int64_t c = 0; c < n; ++c) {      // bf16 of a power of two: its top 16 bits
+    unsigned u; std::memcpy(&u, &inv[c], 4);
+    inv16[c] = (bf16_t)(u >> 16);
+  }
+  TD_CHECK_HIP(hipMemcpyAsync(root->sm_s, sw.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  TD_CHECK_HIP(hipMemcpyAsync(root->sm_inv, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  TD_CHECK_HIP(hipMemcpyAsync(root->sm_inv16, inv16.data(), (size_t)n * 2, hipMemcpyHostToDevice, s));
+  TD_CHECK_HIP(hipMemcpyAsync(root->sm_ext, ext.data(), ext.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  TD_CHECK_HIP(hipStreamSynchronize(s));      // the host vectors go out of scope below
+  // int8 weights again: column factors, and for the LayerNorm-fed ones rows of D + SM_EXT bytes with the replicated channels behind the real ones
+  auto qz = [&](const bf16_t* w, const Fp8Mat& m, int64_t rows, int64_t K, const float* col, const int* ex) -> int {
+    const int ld = (int)(ex ? K + SM_EXT : K);
+    TD_TRY(td_quant_rows_fp8_launch(w, (int)K, m.q, ld, m.s, (int)rows, (int)K, s, 1, nullptr, col));
+    if (ex) TD_TRY(td_ext_cols_launch(m.q, ld, (int)rows, (int)K, ex, SM_EXT, s));
+    return TD_OK;
+  };
+  for (int i = 0; i < L; ++i) {
+    const DoubleW& w = root->dbl[i];
+    const DoubleW8& q = root->dbl8[i];
+    const float* c = root->sm_s + sm_dbl(root, i);
+    const int* ex = root->sm_ext + (size_t)4 * i * SM_EXT;
+    TD_TRY(qz(w.qkv_img_w, q.qkv_img, 3 * D, D, c, ex)); TD_TRY(qz(w.qkv_ctx_w, q.qkv_ctx, 3 * D, D, c + D, ex + SM_EXT));
+    TD_TRY(qz(w.ff1_img_w, q.ff1_img, M, D, c + 2 * D, ex + 2 * SM_EXT)); TD_TRY(qz(w.ff1_ctx_w, q.ff1_ctx, M, D, c + 3 * D, ex + 3 * SM_EXT));
+    TD_TRY(qz(w.ff2_img_w, q.ff2_img, D, M, c + 4 * D, nullptr)); TD_TRY(qz(w.ff2_ctx_w, q.ff2_ctx, D, M, c + 4 * D + M, nullptr));
+  }
+  for (int i = 0; i < Ls; ++i) {
+    const float* c = root->sm_s + sm_sgl(root, i);
+    TD_TRY(qz(root->sgl[i].w1, root->sgl8[i].w1, 3 * D + M, D, c, root->sm_ext + (size_t)(4 * L + i) * SM_EXT));
+    TD_TRY(qz(root->sgl[i].w2, root->sgl8[i].w2, D, D + M, c + D, nullptr));
+  }
+  TD_CHECK_HIP(hipStreamSynchronize(s));      // other contexts' streams read these weights next
+  root->smooth_ready = true;
+  ++root->hist_epoch;                          // scales recorded under the unsmoothed form say nothing about the smoothed one
+  return TD_OK;
+}
+}  // namespace
+
+extern "C" {
+
 // The joint attention of every block: TD_ATTENTION_BF16 (default, the reference graph's arithmetic) or TD_ATTENTION_FP8 -- QK^T and P.V on
 // the e4m3 matrix instruction (csrc/attention_fp8.hip).  Independent of td_flux_set_precision; meant for the 8-bit modes, where the
 // attention is otherwise a quarter of the image.
@@ -565,14 +743,16 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream) {
   TD_CHECK_ARG(f && (precision == TD_PRECISION_BF16 || precision == TD_PRECISION_FP8_E4M3 || precision == TD_PRECISION_INT8), "td_flux_set_precision: unknown precision %d", precision);
   TD_CHECK_ARG(!f->parent, "td_flux_set_precision: set the precision on the parent context (forks follow it)");
   ++f->hist_epoch;
+  f->smooth_ready = false;      // the weights are quantised afresh below, unsmoothed: the next int8 forward calibrates again
   if (precision == TD_PRECISION_BF16) { f->precision = precision; return TD_OK; }
   TD_CHECK_ARG(f->D % 128 == 0 && f->M % 128 == 0, "td_flux_set_precision: fp8 needs inner widths that are multiples of 128");
   hipStream_t s = (hipStream_t)stream;
   const int64_t D = f->D, M = f->M, L = f->cfg.num_layers, Ls = f->cfg.num_single_layers;
   if (!f->arena8) {
     auto al = [](int64_t b) { return (b + 255) & ~int64_t(255); };
-    const int64_t per_double = 2 * (al(3 * D * D) + al(D * D) + al(M * D) + al(D * M)) + 2 * (al(3 * D * 4) + al(D * 4) + al(M * 4) + al(D * 4));
-    const int64_t per_single = al((3 * D + M) * D) + al(D * (D + M)) + al((3 * D + M) * 4) + al(D * 4);
+    const int64_t DE = D + SM_EXT;      // LayerNorm-fed Linears: room for the replicated input channels of the smoothed form
+    const int64_t per_double = 2 * (al(3 * D * DE) + al(D * D) + al(M * DE) + al(D * M)) + 2 * (al(3 * D * 4) + al(D * 4) + al(M * 4) + al(D * 4));
+    const int64_t per_single = al((3 * D + M) * DE) + al(D * (D + M)) + al((3 * D + M) * 4) + al(D * 4);
     const int64_t total = L * per_double + Ls * per_single;
     hipError_t e = hipMalloc((void**)&f->arena8, (size_t)total);
     if (e != hipSuccess) {
@@ -589,10 +769,10 @@ int td_flux_set_precision(td_flux* f, int precision, void* stream) {
     f->dbl8.resize(L);
     f->sgl8.resize(Ls);
     for (auto& w : f->dbl8) {
-      w.qkv_img = take(3 * D, D); w.qkv_ctx = take(3 * D, D); w.out_img = take(D, D); w.out_ctx = take(D, D);
-      w.ff1_img = take(M, D); w.ff1_ctx = take(M, D); w.ff2_img = take(D, M); w.ff2_ctx = take(D, M);
+      w.qkv_img = take(3 * D, DE); w.qkv_ctx = take(3 * D, DE); w.out_img = take(D, D); w.out_ctx = take(D, D);
+      w.ff1_img = take(M, DE); w.ff1_ctx = take(M, DE); w.ff2_img = take(D, M); w.ff2_ctx = take(D, M);
     }
-    for (auto& w : f->sgl8) { w.w1 = take(3 * D + M, D); w.w2 = take(D, D + M); }
+    for (auto& w : f->sgl8) { w.w1 = take(3 * D + M, DE); w.w2 = take(D, D + M); }
   }
   auto qz = [&](const bf16_t* w, const Fp8Mat& m, int64_t rows, int64_t K) {
     return td_quant_rows_fp8_launch(w, (int)K, m.q, (int)K, m.s, (int)rows, (int)K, s, precision == TD_PRECISION_INT8);
@@ -657,6 +837,7 @@ int td_flux_init_random(td_flux* f, uint64_t seed, float std, void* stream) {
   TD_CHECK_ARG(f, "td_flux_init_random: null handle");
   (f->parent ? f->parent : f)->bounds_dirty = true;
   ++(f->parent ? f->parent : f)->hist_epoch;
+  (f->parent ? f->parent : f)->smooth_ready = false;
   TD_TRY(td_fill_normal_bf16(f->arena, f->arena_elems, seed, std, 0.f, stream));
   for (const Slot& s : f->slots)
     if (s.count == 128 && s.name.find(".norm_") != std::string::npos)
@@ -768,7 +949,13 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   // fp8 mode: the LayerNorm-modulate kernel emits e4m3 rows + per-token scales directly; attention / MLP outputs
   // get a per-token quantisation pass; every block GEMM then runs on the fp8 MFMA path.
   const td_flux* root = f->parent ? f->parent : f;   // weights and precision live in the parent context
-  const unsigned m8 = root->precision != TD_PRECISION_BF16 ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
+  // int8 smoothing (td_flux_set_smoothing): the first forward after a change calibrates -- it runs on the bf16 path and collects channel maxima
+  td_flux* const wroot = f->parent ? f->parent : f;
+  const bool sm_mode = root->precision == TD_PRECISION_INT8 && root->smooth_mode == 1;
+  const bool calib = sm_mode && !root->smooth_ready;
+  const bool sm_on = sm_mode && root->smooth_ready;
+  if (calib) TD_CHECK_HIP(hipMemsetAsync(wroot->sm_ax, 0, (size_t)root->smooth_n * 4, s));
+  const unsigned m8 = (root->precision != TD_PRECISION_BF16 && !calib) ? root->fp8_mask : 0u;      // per Linear class (8-bit operand modes)
   // 8-bit attention: its pack pass reads the raw projections and applies QK-norm + RoPE itself (bit-identical, one HBM round trip less)
   // A/B switches are read per call (tests flip them inside one process); three getenv per forward are noise next to ~600 launches
   const bool rope_in_pack = root->attn_mode == TD_ATTENTION_FP8 && getenv("TD_ATTN8_NO_FUSE") == nullptr;      // (the switch: A/B timing and the bit-identity test)
@@ -786,27 +973,39 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   // the LayerNorm ahead of an fp8 Linear writes e4m3 rows + scales, ahead of a bf16 one the bf16 rows
   // history scales (int8): this step quantises the MLP operands under the scales the previous step's maxima give
   const int nT = 2 * L + Ls;
-  const bool hist_mode = q_int8 && root->act_scale_mode == 1;
+  const bool hist_mode = q_int8 && root->act_scale_mode == 1 && !calib;
   const bool use_hist = hist_mode && step > 0 && f->hs_step == step - 1 && f->hs_T == T && f->hs_S == S && f->hs_epoch == root->hist_epoch;
   if (hist_mode) {
     if (use_hist) TD_TRY(td_q8_scales_from_amax_launch(f->hs_amax, f->hs_scale, f->hs_inv, (long long)nT * f->hs_cap, 1.25f, s));
     else TD_CHECK_HIP(hipMemsetAsync(f->hs_amax, 0, (size_t)nT * f->hs_cap * 4, s));
   }
-  auto norm_for = [&](bool fp8) {
-    if (fp8) { np.q = f->xq; np.ldq = D; np.q_scale = f->xs; np.q_int8 = q_int8; } else { np.q = nullptr; np.q_scale = nullptr; }
+  // Smoothed form: the quantised LayerNorm rows and the Linears they feed carry SM_EXT replicated channels behind the D real ones
+  const int DX = sm_on ? D + SM_EXT : D;
+  auto norm_for = [&](bool fp8, const bf16_t* smA = nullptr, const bf16_t* smB = nullptr, const int* exA = nullptr, const int* exB = nullptr) {
+    if (fp8) { np.q = f->xq; np.ldq = DX; np.q_scale = f->xs; np.q_int8 = q_int8; } else { np.q = nullptr; np.q_scale = nullptr; }
+    const bool sm = fp8 && sm_on;
+    np.smoothA = sm ? smA : nullptr; np.smoothB = sm ? smB : nullptr;
+    np.extA = sm ? exA : nullptr; np.extB = sm ? exB : nullptr; np.ext_n = sm ? SM_EXT : 0;
+  };
+  // calibration: channel maxima of rows [r0, r0 + rows) of a bf16 tensor into the smoothing slot `slot`
+  auto cal = [&](const bf16_t* x, int ld, int r0, int rows, int K, int64_t slot) {
+    return td_col_amax_launch(x + (size_t)r0 * ld, ld, rows, K, wroot->sm_ax + slot, s);
   };
   for (int i = 0; i < L; ++i) {
     const DoubleW& w = f->dbl[i];
     const bf16_t* mi = mod + (size_t)i * 12 * D;  // img: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const bf16_t* mc = mi + 6 * D;                // ctx: same order
     np.shiftA = mc; np.scaleA = mc + D; np.shiftB = mi; np.scaleB = mi + D;
-    norm_for(m8 & TD_FP8_QKV);
+    const int64_t sd = sm_dbl(root, i);      // this block's smoothing slots: qkv_img, qkv_ctx, ff1_img, ff1_ctx [D each], ff2_img, ff2_ctx [M each]
+    const int* sx = root->sm_ext + (size_t)4 * i * SM_EXT;      // ... and their replicated-channel tables, same order
+    norm_for(m8 & TD_FP8_QKV, root->sm_inv16 + sd + D, root->sm_inv16 + sd, sx + SM_EXT, sx);
     TD_TRY(norm_rows(f, s, np));
+    if (calib) { TD_TRY(cal(f->xn, D, 0, T, D, sd + D)); TD_TRY(cal(f->xn, D, T, Si, D, sd)); }
     bf16_t* xn_img = f->xn + (size_t)T * D;
     if (m8 & TD_FP8_QKV) {
       const DoubleW8& w8 = root->dbl8[i];
-      TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.qkv_img, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
-                     f->xq, f->xs, w8.qkv_ctx, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
+      TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * DX, f->xs + T, w8.qkv_img, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
+                     f->xq, f->xs, w8.qkv_ctx, w.qkv_ctx_b, f->qkv, T, DX, 3 * D, 3 * D, DX));
     } else {
       TD_TRY(gemm2(f, s, xn_img, w.qkv_img_w, w.qkv_img_b, f->qkv + (size_t)T * 3 * D, Si,
                    f->xn, w.qkv_ctx_w, w.qkv_ctx_b, f->qkv, T, D, 3 * D, 3 * D, D));
@@ -833,8 +1032,9 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
                    f->attn, w.out_ctx_w, w.out_ctx_b, h, T, D, D, D, D, TD_ACT_NONE, mi + 2 * D, mc + 2 * D, true));
     }
     np.shiftA = mc + 3 * D; np.scaleA = mc + 4 * D; np.shiftB = mi + 3 * D; np.scaleB = mi + 4 * D;
-    norm_for(m8 & TD_FP8_FF1);
+    norm_for(m8 & TD_FP8_FF1, root->sm_inv16 + sd + 3 * D, root->sm_inv16 + sd + 2 * D, sx + 3 * SM_EXT, sx + 2 * SM_EXT);
     TD_TRY(norm_rows(f, s, np));
+    if (calib) { TD_TRY(cal(f->xn, D, 0, T, D, sd + 3 * D)); TD_TRY(cal(f->xn, D, T, Si, D, sd + 2 * D)); }
     const bool ff_hist = use_hist && (m8 & TD_FP8_FF1) && (m8 & TD_FP8_FF2);
     float* hsc = f->hs_scale + (size_t)i * f->hs_cap;
     float* hiv = f->hs_inv + (size_t)i * f->hs_cap;
@@ -844,16 +1044,25 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
       Q8Out q_img, q_ctx;
       q_img.q = f->aq + (size_t)T * M; q_img.ld = M; q_img.inv = hiv + T; q_img.amax = ham + T;
       q_ctx.q = f->aq; q_ctx.ld = M; q_ctx.inv = hiv; q_ctx.amax = ham;
-      TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * D, f->xs + T, w8.ff1_img, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
-                     f->xq, f->xs, w8.ff1_ctx, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH, nullptr, nullptr, false,
+      if (sm_on) { q_img.smooth = root->sm_inv16 + sd + 4 * D; q_ctx.smooth = root->sm_inv16 + sd + 4 * D + M; }
+      TD_TRY(gemm2_8(f, s, f->xq + (size_t)T * DX, f->xs + T, w8.ff1_img, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
+                     f->xq, f->xs, w8.ff1_ctx, w.ff1_ctx_b, f->mlp, T, DX, M, M, DX, TD_ACT_GELU_TANH, nullptr, nullptr, false,
                      ff_hist ? &q_img : nullptr, ff_hist ? &q_ctx : nullptr));
     } else {
       TD_TRY(gemm2(f, s, xn_img, w.ff1_img_w, w.ff1_img_b, f->mlp + (size_t)T * M, Si,
                    f->xn, w.ff1_ctx_w, w.ff1_ctx_b, f->mlp, T, D, M, M, D, TD_ACT_GELU_TANH));
+      if (calib) { TD_TRY(cal(f->mlp, M, 0, T, M, sd + 4 * D + M)); TD_TRY(cal(f->mlp, M, T, Si, M, sd + 4 * D)); }
     }
     if (m8 & TD_FP8_FF2) {
       const DoubleW8& w8 = root->dbl8[i];
-      if (!ff_hist) TD_TRY(quant_act(f, s, f->mlp, M, S, M, hist_mode ? ham : nullptr));
+      if (!ff_hist) {
+        if (sm_on) {      // the two streams meet different weights: their own factors
+          TD_TRY(quant_act(f, s, f->mlp, M, T, M, hist_mode ? ham : nullptr, root->sm_inv + sd + 4 * D + M, 0));
+          TD_TRY(quant_act(f, s, f->mlp, M, Si, M, hist_mode ? ham : nullptr, root->sm_inv + sd + 4 * D, T));
+        } else {
+          TD_TRY(quant_act(f, s, f->mlp, M, S, M, hist_mode ? ham : nullptr));
+        }
+      }
       const float* asc = ff_hist ? hsc : f->as_;
       TD_TRY(gemm2_8(f, s, f->aq + (size_t)T * M, asc + T, w8.ff2_img, w.ff2_img_b, h_img, Si,
                      f->aq, asc, w8.ff2_ctx, w.ff2_ctx_b, h, T, M, D, D, M, TD_ACT_NONE, mi + 5 * D, mc + 5 * D, true));
@@ -868,8 +1077,11 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
     const SingleW& w = f->sgl[i];
     const bf16_t* ms = mod + (size_t)L * 12 * D + (size_t)i * 3 * D;  // shift, scale, gate
     np.shiftA = np.shiftB = ms; np.scaleA = np.scaleB = ms + D;
-    norm_for(m8 & TD_FP8_SINGLE_IN);
+    const int64_t ss = sm_sgl(root, i);      // this block's smoothing slots: w1 [D], w2 [D + M] (its first D channels -- the attention half -- stay 1)
+    const int* sxs = root->sm_ext + (size_t)(4 * L + i) * SM_EXT;
+    norm_for(m8 & TD_FP8_SINGLE_IN, root->sm_inv16 + ss, root->sm_inv16 + ss, sxs, sxs);
     TD_TRY(norm_rows(f, s, np));
+    if (calib) TD_TRY(cal(f->xn, D, 0, S, D, ss));
     const bool sg_hist = use_hist && fused_split && (m8 & TD_FP8_SINGLE_IN) && (m8 & TD_FP8_SINGLE_OUT);
     float* hsc = f->hs_scale + (size_t)(L + i) * f->hs_cap;
     float* hiv = f->hs_inv + (size_t)(L + i) * f->hs_cap;
@@ -879,13 +1091,14 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
       if (fused_split) {
         Q8Out q_mlp;
         q_mlp.q = f->aq + D; q_mlp.ld = D + M; q_mlp.inv = hiv; q_mlp.amax = ham;      // the mlp half of [attn | mlp], int8, straight from the epilogue
-        TD_TRY(gemm8(f, s, f->xq, D, f->xs, w8.w1, w.b1, f->qkv, 3 * D, S, 3 * D + M, D, TD_ACT_NONE, nullptr, nullptr, 0,
+        if (sm_on) q_mlp.smooth = root->sm_inv16 + ss + 2 * D - 3 * D;      // indexed by the launch's absolute output column n >= 3 D: w2's MLP channels start at ss + D + D
+        TD_TRY(gemm8(f, s, f->xq, DX, f->xs, w8.w1, w.b1, f->qkv, 3 * D, S, 3 * D + M, DX, TD_ACT_NONE, nullptr, nullptr, 0,
                      f->cat + D, D + M, TD_ACT_GELU_TANH, 3 * D, sg_hist ? &q_mlp : nullptr));
       } else {
         Fp8Mat wa = w8.w1, wb = w8.w1;
-        wb.q += (size_t)3 * D * D; wb.s += 3 * D;
-        TD_TRY(gemm8(f, s, f->xq, D, f->xs, wa, w.b1, f->qkv, 3 * D, S, 3 * D, D));
-        TD_TRY(gemm8(f, s, f->xq, D, f->xs, wb, w.b1 + 3 * D, f->cat + D, D + M, S, M, D, TD_ACT_GELU_TANH));
+        wb.q += (size_t)3 * D * DX; wb.s += 3 * D;
+        TD_TRY(gemm8(f, s, f->xq, DX, f->xs, wa, w.b1, f->qkv, 3 * D, S, 3 * D, DX));
+        TD_TRY(gemm8(f, s, f->xq, DX, f->xs, wb, w.b1 + 3 * D, f->cat + D, D + M, S, M, DX, TD_ACT_GELU_TANH));
       }
     } else if (fused_split) {
       TdGemmParams gp;
@@ -893,6 +1106,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
       gp.C = f->qkv; gp.ldc = 3 * D; gp.act = TD_ACT_NONE;
       gp.C2 = f->cat + D; gp.ldc2 = D + M; gp.act2 = TD_ACT_GELU_TANH; gp.n_split = 3 * D;
       TD_TRY(gemm_p(f, s, gp));
+      if (calib) TD_TRY(cal(f->cat + D, D + M, 0, S, M, ss + 2 * D));
     } else {
       TD_TRY(gemm(f, s, f->xn, D, w.w1, w.b1, f->qkv, 3 * D, S, 3 * D, D));
       TD_TRY(gemm(f, s, f->xn, D, w.w1 + (size_t)3 * D * D, w.b1 + 3 * D, f->cat + D, D + M, S, M, D, TD_ACT_GELU_TANH));
@@ -908,7 +1122,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
       if (sg_hist) {
         // both halves of the operand are in f->aq already: the mlp half from the W1 epilogue, the attention half from the attention epilogue
       } else {
-        TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M, hist_mode ? ham : nullptr));
+        TD_TRY(quant_act(f, s, f->cat, D + M, S, D + M, hist_mode ? ham : nullptr, sm_on ? root->sm_inv + ss + D : nullptr));
       }
       TD_TRY(gemm8(f, s, f->aq, D + M, sg_hist ? hsc : f->as_, root->sgl8[i].w2, w.b2, h, D, S, D, D + M, TD_ACT_NONE, ms + 2 * D, h, D));
     } else {
@@ -924,6 +1138,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
   TD_TRY(norm_rows(f, s, nf));
   TD_TRY(gemm(f, s, f->xn, D, f->proj_w, f->proj_b, (bf16_t*)velocity, C, Si, C, D));
+  if (calib) TD_TRY(finish_smoothing(wroot, s));      // (synchronises s; bumps the history epoch)
   if (hist_mode) { f->hs_step = step; f->hs_T = T; f->hs_S = S; f->hs_epoch = root->hist_epoch; } else f->hs_step = -1;
   if (href_on) { f->href_cur ^= 1; f->href_step = step; f->href_T = T; f->href_S = S; f->href_epoch = root->hist_epoch; } else f->href_step = -1;
   return TD_OK;

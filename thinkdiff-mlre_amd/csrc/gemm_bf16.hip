@@ -48,6 +48,7 @@ __device__ __forceinline__ float apply_act(float x) {
 struct ProbView {
   const bf16_t* bias; const bf16_t* gate; const bf16_t* res; bf16_t* C; int M;
   uint8_t* q8; const float* q8_inv; unsigned* q8_amax;      // int8 output form (TdGemmParams::q8), rows of THIS problem
+  const bf16_t* q8_smooth;                                    // ... and its per-column smoothing factors (may be null)
 };
 
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;   // beyond any descriptor range (operands are < 4 GiB - 64 KiB, checked on the host)
@@ -81,7 +82,9 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
   const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cout, (unsigned)(((long long)(p.M - 1) * ldo + ncols_out) * 2));
   const __amdgpu_buffer_rsrc_t rsR = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * pp.ldr + pp.N) * 2));
   const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.bias, (unsigned)pp.N * 2u);
-  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(p.gate, (unsigned)pp.N * 2u);
+  // (the int8 output form has no gate: its slot of per-column registers carries the smoothing factors instead)
+  const bool q8_sm = q8_here && p.q8_smooth != nullptr;
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(q8_here ? p.q8_smooth : p.gate, (unsigned)pp.N * 2u);
 
   // per-column operands of the lane's NV columns (a null bias / gate reads as zeros; mode 1 always has a gate)
   float bias[NV], gate[NV];
@@ -154,6 +157,10 @@ __device__ __forceinline__ void epilogue(const TdGemmParams& pp, const ProbView&
     if constexpr (Q8 && NV == 16) {
       if (q8_here) {
         round_all();                     // the activation's output is a bf16 tensor in the reference graph
+        if (q8_sm) {
+#pragma unroll
+          for (int c = 0; c < NV; ++c) v[c] *= gate[c];      // 1 / s of the consuming Linear's smoothing: a power of two, exact
+        }
         float am = 0.f;
 #pragma unroll
         for (int c = 0; c < NV; ++c) am = fmaxf(am, fabsf(v[c]));
@@ -279,6 +286,7 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
   pv.C = second_prob ? p.g_C : p.C;
   pv.M = second_prob ? p.g_M : p.M;
   pv.q8 = second_prob ? p.g_q8 : p.q8; pv.q8_inv = second_prob ? p.g_q8_inv : p.q8_inv; pv.q8_amax = second_prob ? p.g_q8_amax : p.q8_amax;
+  pv.q8_smooth = second_prob ? p.g_q8_smooth : p.q8_smooth;
   if (m0 >= pv.M) return;      // (a sub-tile of a split tail tile that lies wholly below the problem's last row; workgroup-uniform)
 
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------

@@ -40,6 +40,9 @@ struct TdGemmParams {
   // (C2) it applies to the second one, the first stays bf16.  g_* = the second problem of a grouped launch.  See the epilogue.
   uint8_t* q8 = nullptr; int ldq8 = 0; const float* q8_inv = nullptr; unsigned* q8_amax = nullptr;
   uint8_t* g_q8 = nullptr; const float* g_q8_inv = nullptr; unsigned* g_q8_amax = nullptr;
+  // int8 OUTPUT only: per-column factors (bf16, indexed by the ABSOLUTE output column n of this launch; null = none) applied to the activated value
+  // before its row maximum and its quantisation -- 1 / s of the int8 smoothing of the Linear that consumes this output
+  const bf16_t* q8_smooth = nullptr; const bf16_t* g_q8_smooth = nullptr;
   const float* a_scale = nullptr; const float* w_scale = nullptr;        // [M], [N]
   const float* g_a_scale = nullptr; const float* g_w_scale = nullptr;    // second problem of a grouped launch
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
@@ -130,10 +133,24 @@ struct TdNormParams {
   // fp8 output (q != null): the row is written as OCP e4m3 q[row, :] = fp8(y / s), s = max|y| / 448 -> q_scale[row]; y unused
   uint8_t* q = nullptr; int ldq = 0; float* q_scale = nullptr;
   int q_int8 = 0;   // q holds symmetric int8 instead: q = rint(y / s), s = max|y| / 127
+  // quantised output only: per-channel factors (bf16 [D], 1 / s of the int8 smoothing, powers of two) applied before the row maximum is taken;
+  // A for rows < split, B for the others; null = none
+  const bf16_t* smoothA = nullptr; const bf16_t* smoothB = nullptr;
+  // ... and replicated channels (int8 only): q rows carry ext_n further bytes behind the D quantised ones, byte D + e = the quantised byte of
+  // channel ext[e] (or 0 where ext[e] < 0).  A channel that runs r x above the rest is divided by r (smooth) and present r times -- the
+  // contraction sums r x (x / r) w -- so its weight column keeps its magnitude and the row's step is set by the rest (outlier channel splitting).
+  const int* extA = nullptr; const int* extB = nullptr; int ext_n = 0;
 };
+// weights of such a Linear: q[r, K + e] = q[r, ext[e]] (0 where ext[e] < 0) for every row of an int8 matrix with row stride ld >= K + ext_n
+int td_ext_cols_launch(uint8_t* q, int ld, int rows, int K, const int* ext, int ext_n, hipStream_t stream);
 // per-row dynamic fp8 quantisation of a bf16 matrix: q[r,:] = e4m3(x[r,:] / s_r), s_r = max|x[r,:]| / 448 (1 for a zero row)
 // int8 = 1: symmetric int8 instead (q = rint(x / s_r), s_r = max|x[r,:]| / 127)
-int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8 = 0, unsigned* amax_out = nullptr);
+// col_mul (fp32 [K], may be null): per-column factors applied first (int8 smoothing: s on a weight's input channels, 1 / s on activations)
+int td_quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int K, hipStream_t stream, int int8 = 0, unsigned* amax_out = nullptr,
+                             const float* col_mul = nullptr);
+// int8 smoothing (csrc/elementwise.hip, bottom): column maxima of a bf16 matrix (atomic max into float bits), and the factors made from two of them
+int td_col_amax_launch(const bf16_t* x, int ldx, int rows, int K, unsigned* amax, hipStream_t stream);
+int td_smooth_factors_launch(const unsigned* ax, const unsigned* aw, int n, float* s, float* inv, bf16_t* inv16, hipStream_t stream);
 // history-scaled int8 (csrc/elementwise.hip, bottom): turn the accumulated maxima into the next step's scales
 int td_q8_scales_from_amax_launch(unsigned* amax, float* scale, float* inv, long long n, float margin, hipStream_t stream);
 int td_norm_rows_launch(const TdNormParams& p, hipStream_t stream);

@@ -60,6 +60,7 @@ def _declare(L):
         "td_flux_set_precision": [vp, i32, vp],
         "td_flux_set_fp8_gemms": [vp, ctypes.c_uint],
         "td_flux_set_act_scales": [vp, i32],
+        "td_flux_set_smoothing": [vp, i32],
         "td_flux_set_attention": [vp, i32],
         "td_flux_prepared_shape": [vp, vp, vp, vp, vp],
         "td_vae_output_shape": [vp, i32, i32, vp, vp, vp],

@@ -153,7 +153,7 @@ class FluxTransformer2DModel:
         self.attention = mode
         return self
 
-    def set_precision(self, precision: str = "bf16", fp8_gemms=None, act_scales: str = "dynamic"):
+    def set_precision(self, precision: str = "bf16", fp8_gemms=None, act_scales: str = "dynamic", smoothing: bool = False):
         """"bf16" (default) or "fp8": e4m3 operands for the block GEMMs (weights quantised per output channel from the
         parameters as loaded now -- call after load_state_dict / init_random; activations per token on the fly).
         fp8_gemms: None = every block Linear, or the classes that take the fp8 path (names of FP8_GEMMS, or the bit mask);
@@ -164,7 +164,10 @@ class FluxTransformer2DModel:
         _hip.check(self._L.td_flux_set_fp8_gemms(self._h, mask))
         # int8 only: "history" = per-token scales of the MLP operands from the previous denoise step (td_flux_set_act_scales)
         _hip.check(self._L.td_flux_set_act_scales(self._h, {"dynamic": 0, "history": 1}[act_scales] if code == 2 else 0))
+        # int8 only: per-channel smoothing of outlier-carrying activations, calibrated on the first forward (td_flux_set_smoothing)
+        _hip.check(self._L.td_flux_set_smoothing(self._h, 1 if (smoothing and code == 2) else 0))
         self.precision, self.fp8_gemms, self.act_scales = ("bf16", "fp8", "int8")[code], mask, (act_scales if code == 2 else "dynamic")
+        self.smoothing = bool(smoothing and code == 2)
         return self
 
     # ---- conditioning / schedule ----------------------------------------------------------------------

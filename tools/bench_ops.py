@@ -342,6 +342,33 @@ def bench_attn8():
         print(f"attn8 S={S} H={H}: " + "   ".join(f"{k} {v*1e3:6.1f} us {fl/v/1e9:6.0f} TF/s" for k, v in best.items()), flush=True)
 
 
+def bench_pack8():
+    """Where the 8-bit attention's pack pass spends its time: the fused form (QK-RMSNorm + RoPE inside the pass, as the engine runs it) with its
+    q / k / v sections switched off in turn (TD_PACK_PROBE; the attention kernel then runs on stale operands -- durations only)."""
+    S, H = 4354, 24
+    W = H * 128
+    pool = [torch.randn(S, 3 * W, device="cuda").bfloat16() for _ in range(6)]
+    out = torch.empty(S, W, device="cuda", dtype=torch.bfloat16)
+    cos, sin = torch.rand(S, 128, device="cuda"), torch.rand(S, 128, device="cuda")
+    wq, wk = torch.ones(128, device="cuda").bfloat16(), torch.ones(128, device="cuda").bfloat16()
+    L = _hip.lib()
+    L.td_attention_fp8_workspace_bytes.restype = __import__("ctypes").c_size_t
+    ws = torch.empty(int(L.td_attention_fp8_workspace_bytes(S, S, H)), dtype=torch.uint8, device="cuda")
+    st = {"i": 0}
+    def f():
+        st["i"] = (st["i"] + 1) % len(pool)
+        _hip.attention_fp8_qk_rope(pool[st["i"]], out, H, cos, sin, split=258, wqA=wq, wkA=wk, wqB=wq, wkB=wk, workspace=ws)
+    res = {}
+    for _ in range(3):
+        for probe in (0, 1, 2, 4, 7):
+            os.environ["TD_PACK_PROBE"] = str(probe)
+            res[probe] = min(res.get(probe, 1e9), timeit(f, iters=10, warmup=2))
+    os.environ.pop("TD_PACK_PROBE")
+    base = res[7]
+    print(f"pack + attention S={S}: all {res[0]*1e3:.1f} us; attention alone (pack sections off) {base*1e3:.1f}; pack {1e3*(res[0]-base):.1f} = "
+          f"v {1e3*(res[0]-res[1]):.1f} + k {1e3*(res[0]-res[2]):.1f} + q {1e3*(res[0]-res[4]):.1f} (+ fixed {1e3*(res[1]+res[2]+res[4]-2*res[0]-base):.1f})", flush=True)
+
+
 def bench_gemmref():
     """External yardstick for the block GEMMs (measurement only; never in the product): torch.nn.functional.linear (= hipBLASLt on
     this image) against td_linear on the six FLUX.1-dev block shapes at the joint sequence length, random operands, same box, same
