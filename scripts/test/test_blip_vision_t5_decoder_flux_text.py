@@ -141,7 +141,7 @@ class ClipFluxDriver:
         self.text = providers.load_text_encoders(run, self.pipe, self.device)
         self.pipe.set_progress_bar_config(disable=True)
         self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"), fp8_gemms=(list(run.get("flux_fp8_gemms")) if run.get("flux_fp8_gemms", None) else None),
-                                            act_scales=run.get("flux_act_scales", "dynamic"))   # "fp8": BASELINE config 5's e4m3 block GEMMs
+                                            act_scales=run.get("flux_act_scales", "dynamic"), smoothing=bool(run.get("flux_smoothing", False)))   # "fp8": BASELINE config 5's e4m3 block GEMMs
         self.pipe.transformer.set_attention(run.get("flux_attention", "bf16"))      # "fp8": QK^T / P.V on the e4m3 MFMA (8-bit modes; td_flux_set_attention)
         self._init_savers()
 

@@ -65,7 +65,7 @@ class LvlmFluxDriver:
             raise FileNotFoundError("no FLUX weights: set run.local_weights.flux to a local diffusers directory or run.synthetic: true")
         self.text = providers.load_text_encoders(run, self.pipe, self.device)
         self.pipe.transformer.set_precision(run.get("flux_precision", "bf16"), fp8_gemms=(list(run.get("flux_fp8_gemms")) if run.get("flux_fp8_gemms", None) else None),
-                                            act_scales=run.get("flux_act_scales", "dynamic"))
+                                            act_scales=run.get("flux_act_scales", "dynamic"), smoothing=bool(run.get("flux_smoothing", False)))
         self.pipe.transformer.set_attention(run.get("flux_attention", "bf16"))      # "fp8": QK^T / P.V on the e4m3 MFMA (8-bit modes; td_flux_set_attention)
         self.pipe.images_in_flight = max(1, int(run.get("images_in_flight", 2)))
         self.pipe.set_progress_bar_config(disable=False)

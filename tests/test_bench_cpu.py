@@ -34,6 +34,7 @@ def test_config5_batch_is_sharded_and_gathered_in_order():
     assert r["scaling"] == "strong" and r["config"]["prompts"] == 9 and r["n_gpus"] == 2 and r["steps"] == 1
     # config 5 names the 8-bit MFMA path; the default is the policy inside the reference tolerance: int8 Linears (history scales) + e4m3 attention
     assert r["dtype"].startswith("int8") and "e4m3" in r["dtype"] and r["config"]["act_scales"] == "history" and r["config"]["attention"] == "fp8"
+    assert r["config"]["smoothing"] == "on" and "smoothing" in r["dtype"]      # ... with the per-channel smoothing that keeps it there on heavy-tailed checkpoints
     r8 = _line(_run("--gpus", "1", "--dry-run", "--workload", "config5", "--prompts", "2", "--precision", "fp8"))
     assert r8["dtype"].startswith("fp8") and r8["config"]["attention"] == "bf16"
     assert abs(r["value"] - 9 / (r["ms_per_step"] / 1e3)) < 1e-6 * r["value"]

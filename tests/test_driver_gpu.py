@@ -55,7 +55,7 @@ def test_driver_groups_images_in_flight_without_changing_them(hip, tmp_path):
     assert digests["bf16", 1] != digests["fp8", 1]
     # the whole 8-bit path through the config surface: int8 Linears under history scales + the e4m3 joint attention
     out = tmp_path / "out_int8_attn8"
-    written = drv.main(base + [f"run.output_dir={out}", "run.images_in_flight=2", "run.flux_precision=int8", "run.flux_act_scales=history", "run.flux_attention=fp8"])
+    written = drv.main(base + [f"run.output_dir={out}", "run.images_in_flight=2", "run.flux_precision=int8", "run.flux_act_scales=history", "run.flux_smoothing=true", "run.flux_attention=fp8"])
     assert len(written) == 4 and all(os.path.getsize(w) > 0 for w in written)
     assert [hashlib.sha256(open(w, "rb").read()).hexdigest() for w in written] != digests["bf16", 1]
 

@@ -143,3 +143,66 @@ def test_int8_history_scales_track_the_dynamic_path(hip):
     print(f"6-step tiny denoise: int8 dynamic~bf16 {d_int8:.4f}  int8 history~bf16 {d_hist:.4f}  history~dynamic {d_hd:.4f}")
     assert torch.isfinite(outs["history"]).all() and torch.equal(outs["history"], outs["history2"])
     assert 0 < d_hd and d_hist < 1.5 * d_int8 + 1e-3
+
+
+def test_int8_smoothing_neutralises_outlier_channels_and_is_inert_without_them(hip):
+    """td_flux_set_smoothing(1) on a tiny model.  (a) A checkpoint without outlier channels: after the calibration forward (bf16 path) the smoothed
+    int8 forward equals the plain int8 forward BIT FOR BIT -- no channel is flagged, every factor is 1, the replicated-channel columns are zero.
+    (b) The same checkpoint with a trained DiT's statistics injected -- residual-stream channels x32 out of both embedders and the blocks' output
+    Linears, MLP intermediate channels x32 with their consuming columns / 32 (tests/full_depth_common.py::stress_plan in miniature): plain int8 loses
+    the bulk of every row to the outliers' step, the smoothed form (outlier channels divided by powers of two, replicated in the contraction or
+    folded into their small weight columns) stays close to bf16."""
+    from oracle import flux_ref as R
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig
+    cfg = R.tiny_config(num_layers=2, num_single_layers=2)
+    D, Mh = cfg.inner_dim, 4 * cfg.inner_dim
+    g = torch.Generator().manual_seed(5)
+    h2 = w2 = 16
+    T = 40
+    lat = torch.randn(1, h2 * w2, 64, generator=g).bfloat16().cuda()
+    pe = torch.randn(1, T, cfg.joint_attention_dim, generator=g).bfloat16().cuda()
+    pool = torch.randn(1, cfg.pooled_projection_dim, generator=g).bfloat16().cuda()
+    img_ids, txt_ids = R.latent_image_ids(h2, w2), torch.zeros(T, 3)
+    t, gd = torch.tensor([0.7324]).bfloat16().cuda(), torch.tensor([3.5])
+    rel = lambda a, b: float((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt())
+
+    def model(sd):
+        m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=2, num_single_layers=2, num_attention_heads=cfg.num_attention_heads,
+                                                         joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                                   max_img_tokens=256, max_txt_tokens=64, max_steps=4)
+        m.load_state_dict(sd)
+        return m
+
+    def run(m, **kw):
+        m.set_precision(**kw)
+        outs = [m.forward(lat, pe, pool, t, img_ids, txt_ids, gd)[0].clone() for _ in range(2)]      # with smoothing, the first forward calibrates
+        torch.cuda.synchronize()
+        return outs[1]
+    plain = R.init_weights(cfg, seed=6)
+    m = model(plain)
+    b16, i8, i8s = run(m, precision="bf16"), run(m, precision="int8"), run(m, precision="int8", smoothing=True)
+    assert torch.equal(i8s, i8), "without outlier channels the smoothed form must be the plain one"
+    hot = {k: v.clone() for k, v in plain.items()}
+    res_ch, mlp_ch = (3, 200, 411), (5, 700, 1500, 2040)
+    for name in hot:
+        lin = name.rsplit(".", 1)[0]
+        if lin in ("x_embedder", "context_embedder") or lin.endswith(("attn.to_out.0", "attn.to_add_out", "ff.net.2", "ff_context.net.2", "proj_out")):
+            for c in res_ch:
+                if hot[name].shape[0] == D:
+                    hot[name][c] *= 32.0 if lin.endswith("embedder") else 8.0
+        if lin.endswith(("ff.net.0.proj", "ff_context.net.0.proj", "proj_mlp")):
+            for c in mlp_ch:
+                hot[name][c] *= 32.0
+        if lin.endswith(("ff.net.2", "ff_context.net.2")) and name.endswith(".weight"):
+            for c in mlp_ch:
+                hot[name][:, c] /= 32.0
+        if lin.endswith("proj_out") and lin.startswith("single") and name.endswith(".weight"):
+            for c in mlp_ch:
+                hot[name][:, D + c] /= 32.0
+    m = model(hot)
+    b16, i8, i8s, i8sh = run(m, precision="bf16"), run(m, precision="int8"), run(m, precision="int8", smoothing=True), None
+    e_plain, e_smooth = rel(i8, b16), rel(i8s, b16)
+    print(f"tiny model with outlier channels: int8~bf16 {e_plain:.4f}, smoothed int8~bf16 {e_smooth:.4f}")
+    assert torch.isfinite(i8s.float()).all()
+    assert e_smooth < 0.5 * e_plain and e_smooth < 3e-2
+    m.set_precision("bf16")

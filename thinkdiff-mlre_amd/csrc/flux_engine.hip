@@ -1134,6 +1134,7 @@ int td_flux_forward(td_flux* f, const void* latents, int step, void* velocity, v
   const bf16_t* mf = mod + (size_t)L * 12 * D + (size_t)Ls * 3 * D;
   TdNormParams nf = np;
   nf.q = nullptr;   // the final projection stays bf16
+  nf.smoothA = nf.smoothB = nullptr; nf.extA = nf.extB = nullptr; nf.ext_n = 0;
   nf.x = h_img; nf.y = f->xn; nf.rows = Si; nf.split = 0;
   nf.scaleA = nf.scaleB = mf; nf.shiftA = nf.shiftB = mf + D;
   TD_TRY(norm_rows(f, s, nf));
