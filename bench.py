@@ -226,15 +226,18 @@ def _policy_parity(key):
 
 
 def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` ("td_gemm_bf16_nt_kernel<8,4>" ...) from the newest committed PMC passes.  The kernel's launch forms (the
+    trailing template arguments: tail split 1 / 2 / 4) are separate entries of the record: their launch-weighted mean is what one launch moved."""
     import glob
-    want = kernel.replace(" ", "").rstrip(">") + ","      # "td_gemm_bf16_nt_kernel<8,4," + pipeline variant, non-conv
+    want = kernel.replace(" ", "").rstrip(">") + ",false,false,false"      # bf16, no conv: "td_gemm_bf16_nt_kernel<8,4,false,false,false" (+ ">" or ",TAIL>")
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         with open(fn) as fh:
             prof = json.load(fh)
-        for name, v in prof["kernels"].items():
-            if want in name.replace(" ", "") and "false,false>" in name.replace(" ", ""):       # not the conv / fp8 instantiations
-                return {"traffic": v["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
-                        "traffic_source": f"{os.path.basename(fn)}: {prof['source']}; {prof['correction']}"}
+        hit = [v for name, v in prof["kernels"].items() if want in name.replace(" ", "")]
+        n = sum(v["launches"] for v in hit)
+        if n:
+            return {"traffic": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n, "traffic_unit": "bytes/launch",
+                    "traffic_source": f"{os.path.basename(fn)}: {prof['source']}; {prof['correction']}"}
     return {"traffic": None}
 
 

@@ -235,7 +235,7 @@ def test_full_depth_8bit_policies_on_the_stress_checkpoint(full_model):
 
 
 def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
-    """Full size, 3 denoise steps per policy: the tail split of the 256 x 256 GEMM tile (csrc/gemm_bf16.hip) against the plain one-tile-per-workgroup
+    """Full size, 3 denoise steps per policy: the (opt-in) tail split of the 256 x 256 GEMM tile (csrc/gemm_bf16.hip) against the plain one-tile-per-workgroup
     launch -- bit-identical latents in bf16, int8 (dynamic and history scales: the int8-output epilogue) and with the e4m3 attention."""
     fx = _fixture("cfg5_T258")
     assert fx["weights_checksum"] == full_model.ensure("plain")
@@ -251,10 +251,12 @@ def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
         torch.cuda.synchronize()
         return out
     for prec in ("bf16", "int8", "int8_history", "int8_history_attn8", "int8_smooth_history_attn8"):
-        monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
+        monkeypatch.delenv("TD_GEMM_TAIL", raising=False)
         base = run(prec)
-        monkeypatch.delenv("TD_GEMM_NO_TAIL")
-        assert torch.equal(run(prec), base), f"{prec}: the tail-split GEMM launches changed the latents"
+        monkeypatch.setenv("TD_GEMM_TAIL", "auto")
+        got = run(prec)
+        monkeypatch.delenv("TD_GEMM_TAIL")
+        assert torch.equal(got, base), f"{prec}: the tail-split GEMM launches changed the latents"
     tr.set_precision("bf16")
     tr.set_attention("bf16")
 

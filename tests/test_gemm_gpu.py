@@ -169,7 +169,8 @@ def test_linear_grouped_ragged_text_rows(hip, cfg):
 @pytest.mark.parametrize("M0,M1,N,K", [(4096, 193, 12288, 256), (4096, 258, 9216, 128), (4354, 0, 21504, 128), (4096, 193, 4352, 512)])
 def test_linear_tail_split_is_bit_identical(hip, monkeypatch, M0, M1, N, K, split):
     """Tile counts that leave a mostly empty last round of the 256 CUs (816 = 3.19 rounds, 648 = 2.5, 1 512 = 5.9 with ragged tiles, 289): the launcher
-    cuts the last tiles into 2 or 4 row sub-tiles (csrc/gemm_bf16.hip, TAIL).  Every output element is still one workgroup's full contraction, so the
+    can cut the last tiles into 2 or 4 row sub-tiles (csrc/gemm_bf16.hip, TAIL; opt-in through TD_GEMM_TAIL since the whole-image A/B went against
+    it -- see the launcher's comment).  Every output element is still one workgroup's full contraction, so the
     result must equal the unsplit launch BIT FOR BIT -- with the grouped two-problem form, ragged last tiles, the gate / residual and GELU epilogues,
     int8 and e4m3 operands."""
     g = torch.Generator().manual_seed(M0 + N + K)
@@ -191,11 +192,9 @@ def test_linear_tail_split_is_bit_identical(hip, monkeypatch, M0, M1, N, K, spli
         yf = hip.linear_fp8(xf, xfs, wf, wfs, b0, tile_cfg=0)
         torch.cuda.synchronize()
         return d0, d1, e0, y8, yf
-    monkeypatch.setenv("TD_GEMM_NO_TAIL", "1")
-    base = run()
-    monkeypatch.delenv("TD_GEMM_NO_TAIL")
-    if split != "auto":
-        monkeypatch.setenv("TD_GEMM_TAIL", split)
+    monkeypatch.delenv("TD_GEMM_TAIL", raising=False)
+    base = run()                                    # the default: one tile per workgroup
+    monkeypatch.setenv("TD_GEMM_TAIL", split)       # "auto": the launcher's own choice of 1 / 2 / 4
     got = run()
     for a, b in zip(got, base):
         if a is not None:

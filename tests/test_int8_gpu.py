@@ -206,3 +206,57 @@ def test_int8_smoothing_neutralises_outlier_channels_and_is_inert_without_them(h
     assert torch.isfinite(i8s.float()).all()
     assert e_smooth < 0.5 * e_plain and e_smooth < 3e-2
     m.set_precision("bf16")
+
+
+def test_history_is_per_image_and_per_configuration(hip):
+    """History scales (int8) and history reference points (e4m3 attention) are the previous step's state OF THE SAME IMAGE UNDER THE SAME NUMERIC
+    CONFIGURATION.  A forward at step k > 0 that follows ANOTHER image's step k - 1 (partial schedules, img2img, two conditions per step), or a change
+    of precision / Linear classes / scale mode / attention mode between two steps, must run the self-contained (dynamic) path: bit-equal to a context
+    that never had a history.  (Before round 4 it inherited the other image's per-token maxima as clip scales, and after a precision switch scales of
+    ~1e-32 from all-zero maxima.)"""
+    from oracle import flux_ref as R
+    from thinkdiff.models.flux_transformer import FluxTransformer2DModel, FluxTransformerConfig, effective_scalar
+    cfg = R.tiny_config(num_layers=2, num_single_layers=2)
+    sd = R.init_weights(cfg, seed=12)
+    m = FluxTransformer2DModel(FluxTransformerConfig(num_layers=2, num_single_layers=2, num_attention_heads=cfg.num_attention_heads,
+                                                     joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim),
+                               max_img_tokens=1024, max_txt_tokens=64, max_steps=8)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    h2 = w2 = 24
+    T, n = 40, 6
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16().cuda()
+    latA, latB, peA, peB, poolA, poolB = mk(h2 * w2, 64), mk(h2 * w2, 64) * 3, mk(T, cfg.joint_attention_dim), mk(T, cfg.joint_attention_dim) * 2, mk(cfg.pooled_projection_dim), mk(cfg.pooled_projection_dim)
+    sig = R.make_sigmas(n, h2 * w2)
+    ts = [effective_scalar(float(s) * 1000.0, torch.bfloat16) for s in sig[:-1]]
+
+    def cond(pe, pool):
+        m.set_condition(pe, pool, R.latent_image_ids(h2, w2))
+        m.set_timesteps(ts, 3500.0)
+    for kw, att in ((dict(precision="int8", act_scales="history"), "bf16"), (dict(precision="int8", act_scales="history"), "fp8"), (dict(precision="bf16"), "fp8")):
+        # reference: image B's step 3 on a context with no history at all (dynamic scales / first-tile references are what a history-less step uses)
+        m.set_precision(**kw)
+        m.set_attention(att)
+        cond(peB, poolB)
+        want = m.forward_step(latB, 3).clone()
+        # image A runs steps 0..2, then image B's conditioning arrives and ITS step 3 is asked for
+        cond(peA, poolA)
+        for i in range(3):
+            m.forward_step(latA, i)
+        cond(peB, poolB)
+        got = m.forward_step(latB, 3).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"{kw} / attention {att}: step 3 of a new image used the previous image's history"
+        # a configuration switch between two consecutive steps of one image: step 3 after steps 0..2 in ANOTHER mode == a history-less step 3
+        cond(peB, poolB)
+        m.set_precision("bf16")
+        m.set_attention("bf16")
+        for i in range(3):
+            m.forward_step(latB, i)
+        m.set_precision(**kw)
+        m.set_attention(att)
+        got2 = m.forward_step(latB, 3).clone()
+        torch.cuda.synchronize()
+        assert torch.isfinite(got2.float()).all() and torch.equal(got2, want), f"{kw} / attention {att}: history survived a precision / attention switch"
+    m.set_precision("bf16")
+    m.set_attention("bf16")

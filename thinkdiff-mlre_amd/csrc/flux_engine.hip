@@ -94,6 +94,7 @@ struct td_flux {
   uint8_t *xq = nullptr, *aq = nullptr;     // per-context, part of the workspace
   char* attn_ws = nullptr;                  // hand-off workspace of the persistent attention kernel (per context: contexts run concurrently)
   int attn_variant = 0;                     // 0: persistent (stream-K) joint attention; 1: one workgroup per (query tile, head) item
+  bool shared_chip = false;                 // several images in flight (td_flux_denoise_multi): kernels of other contexts fill this one's empty rounds
   int attn_mode = 0;                        // parent: TD_ATTENTION_BF16 / TD_ATTENTION_FP8 (td_flux_set_attention)
   char* attn8_ws = nullptr;                 // packed e4m3 q | k | v^T of the 8-bit attention (per context)
   // 8-bit attention, history reference points (TdAttnParams::ref_in / ref_out): per (block, head, token) where the softmax of the NEXT denoise step
@@ -178,7 +179,11 @@ struct TraceScope {
   }
 };
 
-int gemm_p(td_flux* f, hipStream_t s, const TdGemmParams& p) {
+// With several images in flight the partial last round of a GEMM is filled by the other images' kernels, and the tail split's smaller sub-tiles
+// only cost (same-box A/B, 2 in flight: bf16 0.580 with the split vs 0.583 without, int8 0.964 vs 0.968): the engine then asks for plain launches.
+int gemm_p(td_flux* f, hipStream_t s, const TdGemmParams& p0) {
+  TdGemmParams p = p0;
+  p.no_tail = f->shared_chip;
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K);
   TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * (p.M + p.g_M) * p.N * p.K);
   return td_gemm_launch(p, s);
@@ -217,6 +222,7 @@ int gemm8(td_flux* f, hipStream_t s, const uint8_t* A, int lda, const float* a_s
   p.bias = b; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.act = act; p.gate = gate; p.res = res; p.ldr = ldr;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.n_split = n_split;
   if (q8) { p.q8 = q8->q; p.ldq8 = q8->ld; p.q8_inv = q8->inv; p.q8_amax = q8->amax; p.q8_smooth = q8->smooth; }
+  p.no_tail = f->shared_chip;
   const int cfg = td_gemm_config_id(M, N, K / 2);
   TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * M * N * K);
   return td_gemm_launch(p, s);
@@ -237,6 +243,7 @@ int gemm2_8(td_flux* f, hipStream_t s, const uint8_t* A0, const float* as0, cons
   p.g_A = (const bf16_t*)A1; p.g_a_scale = as1; p.g_W = (const bf16_t*)W1.q; p.g_w_scale = W1.s; p.g_bias = b1; p.g_C = C1; p.g_M = M1;
   p.g_gate = gate1; p.g_res = residual ? C1 : nullptr;
   p.lda = ld_a; p.ldc = ld_c; p.ldr = ld_c; p.N = N; p.K = K; p.act = act;
+  p.no_tail = f->shared_chip;
   const int cfg = td_gemm_config_id(M0 + M1, N, K / 2);
   TraceScope ts(f, s, cfg == 0 ? TD_TRACE_GEMM_MAIN : cfg == 3 ? TD_TRACE_GEMM_288 : TD_TRACE_GEMM_OTHER, 2.0 * (M0 + M1) * N * K);
   return td_gemm_launch(p, s);
@@ -1197,7 +1204,7 @@ int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, c
   // and shuts them out (measured, 3 in flight: 0.698 images/s persistent vs 0.71 plain; one image alone: 0.678 vs 0.655).
   static const char* force = getenv("TD_FLUX_INFLIGHT_ATTN");      // experiments only: 0 / 1 forces the attention form used with images in flight
   const int multi_variant = force ? atoi(force) : 1;
-  for (int k = 0; k < count; ++k) fs[k]->attn_variant = count > 1 ? multi_variant : 0;
+  for (int k = 0; k < count; ++k) { fs[k]->attn_variant = count > 1 ? multi_variant : 0; fs[k]->shared_chip = count > 1; }
   int rc = TD_OK;
   for (int i = 0; i < n && rc == TD_OK; ++i)
     for (int k = 0; k < count && rc == TD_OK; ++k) {
@@ -1206,7 +1213,7 @@ int td_flux_denoise_multi(td_flux* const* fs, void* const* latents, int count, c
       if (rc == TD_OK)
         rc = td_euler_step_launch((bf16_t*)latents[k], f->vout, sigmas[i + 1] - sigmas[i], (long long)f->S_img * f->cfg.in_channels, (hipStream_t)streams[k]);
     }
-  for (int k = 0; k < count; ++k) fs[k]->attn_variant = 0;
+  for (int k = 0; k < count; ++k) { fs[k]->attn_variant = 0; fs[k]->shared_chip = false; }
   return rc;
 }
 

@@ -18,6 +18,7 @@
 //  * blockIdx -> tile mapping is XCD-aware (bijective remap + grouped M ordering) so the 32
 //    tiles resident on one XCD share A/W panels through that XCD's L2.
 #include <atomic>
+#include <cstring>
 
 #include "td_common.h"
 #include "td_kernels.h"
@@ -688,9 +689,19 @@ int cu_count() {
 // Tail split of a grid of `tiles` equal tiles on `cus` CUs (one workgroup per CU): the launch takes ceil(tiles / cus) tile times.  Cutting the
 // last `rem = tiles mod cus` tiles into s sub-tiles makes it floor(tiles / cus) + ceil(rem s / cus) / s x (what the smaller tile loses in
 // efficiency: measured ~8 % at s = 2, ~15 % at s = 4).  Returns the best s in {1, 2, 4} -- 1 unless a split saves at least 4 % of the launch.
+//
+// OFF BY DEFAULT (TD_GEMM_TAIL=auto|2|4 turns it on).  A lone cold-weight launch gains what the model says (q|k|v -12 %, ff.net.0 -14 % bf16; -7 / -8 %
+// int8, profiles/r4_gemm_probe.log) -- and the whole image LOSES: same box, same process, alternated three times, one image in flight: bf16 0.5783 with
+// the split vs 0.5846 images/s without, the 8-bit policy 0.907 vs 0.922; two in flight 0.580 vs 0.583 / 0.964 vs 0.968
+// (profiles/r4_tail_split_ab.log).  On real data this chip runs the denoise loop at a clock set by its power budget: an idle end of a round is
+// power the other rounds get back as clock, while the sub-tiles that fill it move 1.5-2.5 x the operand bytes per FLOP (the guide's rule 28:
+// what pays is energy per FLOP, not occupancy).  Kept as a launch form with its bit-identity tests because the conclusion depends on the regime
+// (a device that is not power-limited on this loop would gain the cold-launch figure).
 int tail_split(long long tiles, int cus) {
-  if (getenv("TD_GEMM_NO_TAIL")) return 1;      // (A/B switch; read per launch so one process can time both)
-  if (const char* f = getenv("TD_GEMM_TAIL")) return atoi(f) == 2 || atoi(f) == 4 ? atoi(f) : 1;
+  const char* f = getenv("TD_GEMM_TAIL");      // (read per launch so one process can time every form)
+  if (!f || getenv("TD_GEMM_NO_TAIL")) return 1;
+  if (atoi(f) == 2 || atoi(f) == 4) return atoi(f);
+  if (strcmp(f, "auto") != 0) return 1;
   const long long full = tiles / cus, rem = tiles % cus;
   if (rem == 0 || full == 0) return 1;          // (less than one round: the tile chooser already picks a smaller tile there)
   const double base = (double)(full + 1);
@@ -716,7 +727,7 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   int grid = p.tiles_m * p.tiles_n;
   if constexpr (TAIL == 1 && WM == 8 && WN == 4 && !CONV) {      // the 256 x 256 tile of the block Linears: see whether its last round is worth cutting up
-    const int s = tail_split(grid, cu_count());
+    const int s = p.no_tail ? 1 : tail_split(grid, cu_count());
     if (s == 2) return launch_cfg<WM, WN, CONV, FP8, I8, 2>(p0, stream);
     if (s == 4) return launch_cfg<WM, WN, CONV, FP8, I8, 4>(p0, stream);
   }

@@ -48,6 +48,7 @@ struct TdGemmParams {
   int tiles_m = 0, tiles_m0 = 0, tiles_n = 0;  // filled by the launcher
   int ragged_rows = 64;                        // filled by the launcher: tiles with at most this many rows take the ragged loop (0 with TD_GEMM_NO_RAGGED: A/B)
   int tail_first_wg = 0;                       // filled by the launcher (tail-split launches): workgroups from here on take a sub-tile of the last tiles
+  int no_tail = 0;                             // caller's hint: other kernels share the chip (several images in flight) -- an empty last round gets filled anyway, do not split it
   int probe = 0;                               // filled by the launcher from TD_GEMM_PROBE (timing experiments, results WRONG): 1 = no epilogue, 2 = no k-loop
 };
 

@@ -138,9 +138,9 @@ def bench_gemmprobe():
             _hip.linear_int8(xi, xis, wq, ws, b, act=_hip.ACT_GELU_TANH, out=y, tile_cfg=0)
         for tail in ("off", "on"):
             if tail == "off":
-                os.environ["TD_GEMM_NO_TAIL"] = "1"
+                os.environ.pop("TD_GEMM_TAIL", None)
             else:
-                os.environ.pop("TD_GEMM_NO_TAIL", None)
+                os.environ["TD_GEMM_TAIL"] = "auto"
             row = []
             for kind, f in (("bf16", f_bf16), ("int8", f_int8)):
                 t = {}
