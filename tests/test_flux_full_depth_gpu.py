@@ -221,6 +221,9 @@ def test_full_depth_fp8_policies_vs_oracle_fixture(full_model):
     # ... and with the joint attention on the e4m3 MFMA as well (td_flux_set_attention): alone on the bf16 Linears, and under the whole 8-bit path
     assert res["bf16_attn8"]["pixel_rmse_vs_oracle"] < 1e-2, f"bf16 Linears + e4m3 attention: pixels {res['bf16_attn8']['pixel_rmse_vs_oracle']:.4f} exceed the 1e-2 bar"
     assert res["int8_history_attn8"]["pixel_rmse_vs_oracle"] < 1e-2, f"int8 (history) + e4m3 attention: pixels {res['int8_history_attn8']['pixel_rmse_vs_oracle']:.4f} exceed the 1e-2 bar"
+    # ... and the smoothed forms are the plain ones here (no channel of this checkpoint is an outlier): same level
+    for k in ("int8_smooth", "int8_smooth_history", "int8_smooth_history_attn8"):
+        assert res[k]["pixel_rmse_vs_oracle"] < 1e-2, f"{k}: {res[k]['pixel_rmse_vs_oracle']:.4f} exceeds the 1e-2 bar on the plain fixture"
 
 
 def test_full_depth_8bit_policies_on_the_stress_checkpoint(full_model):
@@ -229,9 +232,13 @@ def test_full_depth_8bit_policies_on_the_stress_checkpoint(full_model):
     bar on BOTH fixtures.  Asserted: every policy stays finite, bf16 holds the bar, and the policy bench.py ships as its 8-bit line holds it too."""
     res = _grade_policies(full_model, "stress_T258")
     assert res["bf16"]["pixel_rmse_vs_oracle"] < 1e-2
-    shipped = os.environ.get("TD_SHIPPED_8BIT_POLICY", "")
-    if shipped:
-        assert res[shipped]["pixel_rmse_vs_oracle"] < 1e-2, f"{shipped}: {res[shipped]['pixel_rmse_vs_oracle']:.4f} on the stress fixture"
+    # what round 4 found and the smoothing exists for: per-token int8 collapses under outlier channels (2.9e-2), e4m3 does not care about them (its
+    # own mantissa noise, 1.6e-2), and int8 with per-channel smoothing + outlier-channel replication is back at the plain checkpoint's level
+    assert res["int8"]["pixel_rmse_vs_oracle"] > 1.5e-2, "plain int8 is expected to break on this checkpoint: if it does not, the fixture lost its outliers"
+    for k in ("int8_smooth", "int8_smooth_history", "int8_smooth_history_attn8", "bf16_attn8"):
+        assert res[k]["pixel_rmse_vs_oracle"] < 1e-2, f"{k}: {res[k]['pixel_rmse_vs_oracle']:.4f} on the heavy-tailed fixture exceeds the 1e-2 bar"
+    shipped = os.environ.get("TD_SHIPPED_8BIT_POLICY", "int8_smooth_history_attn8")      # bench.py's default 8-bit policy (--workload config5)
+    assert res[shipped]["pixel_rmse_vs_oracle"] < 1e-2, f"{shipped}: {res[shipped]['pixel_rmse_vs_oracle']:.4f} on the stress fixture"
 
 
 def test_gemm_launch_forms_do_not_change_the_engine(full_model, monkeypatch):
