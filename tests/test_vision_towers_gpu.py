@@ -71,6 +71,36 @@ def test_qwen2_vision_matches_transformers(hip):
     assert got.pooler_output.shape == (S // 4, 256) and e1 < 2e-2 and e2 < 2e-2
 
 
+def test_qwen2_vision_full_size_matches_transformers(hip):
+    """The released Qwen2-VL-7B tower's SHAPE (32 layers, width 1280, 16 heads of 80, MLP x4, merger -> 3584; 675 M parameters, transformers' own
+    random init) on config 3's image grid (224 x 224 -> 16 x 16 patches -> 64 merged tokens, the grid of tests/golden/full_depth_cfg3_lvlm7b.pt) plus
+    a larger second image, against `Qwen2VisionTransformerPretrainedModel` itself run on the host in bf16 AND in fp32.  32 random layers amplify
+    rounding noise, so the bar is the one the decoder's full-size test uses: HIP no further from the exact (fp32) result than 1.5 x the module's own
+    bf16 run is."""
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLVisionConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VisionTransformerPretrainedModel
+    from thinkdiff.models.vision_towers import HipQwen2VisionTransformer
+    torch.manual_seed(3)
+    cfg = Qwen2VLVisionConfig(depth=32, embed_dim=1280, hidden_size=3584, num_heads=16, mlp_ratio=4, patch_size=14, temporal_patch_size=2,
+                              spatial_merge_size=2, in_channels=3)
+    ref32 = Qwen2VisionTransformerPretrainedModel(cfg).eval()
+    grid = torch.tensor([[1, 16, 16], [1, 20, 28]])                  # 256 + 560 patches -> 64 + 140 merged tokens
+    S = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+    patches = torch.randn(S, 3 * 2 * 14 * 14).bfloat16()
+    sd16 = {k: v.bfloat16() for k, v in ref32.state_dict().items()}
+    with torch.no_grad():
+        ref32.load_state_dict({k: v.float() for k, v in sd16.items()})       # the same bf16-representable weights on every side
+        exact = ref32(patches.float(), grid_thw=grid).pooler_output
+        want16 = ref32.bfloat16()(patches, grid_thw=grid).pooler_output
+    tower = HipQwen2VisionTransformer(sd16, num_heads=16)
+    got = tower(patches.float(), grid).pooler_output
+    torch.cuda.synchronize()
+    e_hip, e_ref, e_pair = _rel(got, exact), _rel(want16, exact), _rel(got, want16)
+    print(f"Qwen2-VL-7B-shaped ViT, 204 merged tokens: HIP vs exact {e_hip:.4f}, transformers bf16 vs exact {e_ref:.4f}, HIP vs transformers bf16 {e_pair:.4f}")
+    assert got.shape == (S // 4, 3584) and torch.isfinite(got.float()).all()
+    assert e_hip < 1.5 * e_ref + 2e-3 and e_pair < 2.5 * e_ref + 2e-3
+
+
 def test_rope_half_and_patchify_exact(hip):
     """Bit-level checks of the two data-movement kernels against torch on the same device."""
     from thinkdiff import _hip

@@ -26,6 +26,17 @@ __device__ __forceinline__ float dot8q(const u32x4_t& a, const u32x4_t& b) {
   return acc;
 }
 
+// Sum over the 16 lanes of a DPP row, every lane ending with the total: four rotate-and-add VALU instructions (row_ror 8, 4, 2, 1).  The
+// `__shfl_xor(s, off, 16)` butterfly this replaces compiles to ds_bpermute -- four DEPENDENT trips through the LDS crossbar per score, ~230 per
+// workgroup at 300 keys and three query heads: that chain, not the K/V stream, was most of the kernel's 23 us at 64 sequences (round 4).
+__device__ __forceinline__ float row_sum16(float s) {
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xf, 0xf, false));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xf, 0xf, false));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xf, 0xf, false));
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xf, 0xf, false));
+  return s;
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams p) {
   __shared__ float sm_m[4][G], sm_l[4][G];
@@ -59,10 +70,7 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
     for (int i = 0; i < 4; ++i) { vf[2 * i] = bf_lo(vv[i]); vf[2 * i + 1] = bf_hi(vv[i]); }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float s = dot8q(kk, q[g]);
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
-      s *= sc;
+      float s = row_sum16(dot8q(kk, q[g])) * sc;
       const float mn = fmaxf(m[g], s);
       const float corr = __builtin_amdgcn_exp2f(m[g] - mn), pe = __builtin_amdgcn_exp2f(s - mn);
       m[g] = mn;

@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   const bf16_t* xr = p.x + (size_t)row * p.ldx;
+  // replicated channels (int8 smoothing): this lane's two table entries are fetched with the row, not behind the arithmetic that needs them last
+  int ext_s0 = -1, ext_s1 = -1;
+  {
+    const int* ext0 = row >= p.split ? p.extB : p.extA;
+    if (p.q && ext0 && lane * 2 < p.ext_n) { ext_s0 = ext0[lane * 2]; ext_s1 = ext0[lane * 2 + 1]; }
+  }
   float v[NCH][8];
   float sum = 0.f;
 #pragma unroll
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void td_norm_rows_kernel(const TdNormParams p)
     }
     if (ext) {      // (wave-uniform; a wave reads only what it wrote itself: LDS operations of a wave complete in order)
       for (int e = lane * 2; e < p.ext_n; e += 128) {
-        const int s0 = ext[e], s1 = ext[e + 1];
+        const int s0 = e < 128 ? ext_s0 : ext[e], s1 = e < 128 ? ext_s1 : ext[e + 1];
         const unsigned b0 = s0 >= 0 ? qrow[threadIdx.x >> 6][s0] : 0u, b1 = s1 >= 0 ? qrow[threadIdx.x >> 6][s1] : 0u;
         *(unsigned short*)(qr + NCH * 512 + e) = (unsigned short)(b0 | (b1 << 8));
       }

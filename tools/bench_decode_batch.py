@@ -8,7 +8,11 @@ from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
 shapes = {"2B": Qwen2VLTextConfig(hidden_size=1536, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2, intermediate_size=8960,
                                   vocab_size=151936, tie_word_embeddings=True),
           "7B": Qwen2VLTextConfig()}
-which = [a for a in sys.argv[1:] if not a.isdigit()] or ["2B", "7B"]
+group = [int(a[2:]) for a in sys.argv[1:] if a.startswith("G=")]      # G=<q heads per workgroup of the decode attention>: A/B of td_attention_decode_set_group
+if group:
+    from thinkdiff import _hip
+    _hip.lib().td_attention_decode_set_group(group[0])
+which = [a for a in sys.argv[1:] if not a.isdigit() and not a.startswith("G=")] or ["2B", "7B"]
 batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 4, 8, 16, 24, 32, 48, 64]
 CACHE = 300
 for name in which:
