@@ -396,6 +396,10 @@ int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, cons
 int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
                               const int* lens, void* hidden_out, void* logits_last, void* stream);
 int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache rows of an existing handle */
+/* Decode step: the rotary embedding of the new q / k rows and the write of the new k | v rows into the cache happen inside the decode-attention
+ * launch (default, one launch per layer fewer) or in a launch of their own (on = 0: A/B and the bit-identity test).  Same arithmetic either way
+ * (the vLLM fork's rotary_emb + cache write, thinkdiff/models/mllama_vllm_t5_embed_decoder_2.py:1083).  Returns the previous setting. */
+int td_qwen2_set_fused_rope(td_qwen2* f, int on);
 int td_qwen2_slot_capacity(const td_qwen2* f);
 /* copy the first `len` cache rows of sequence src to sequence dst (compaction when a sequence finishes) */
 int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream);

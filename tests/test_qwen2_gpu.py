@@ -201,6 +201,39 @@ def test_decode_attention_groups_q_heads_of_a_kv_head(hip, Hq, Hkv, G):
     assert _rel(outs[G][0], outs[1][0]) < 2e-3 and _rel(outs[G][1], outs[1][1]) < 2e-3
 
 
+@pytest.mark.parametrize("Hq,Hkv,G", [(12, 2, 1), (12, 2, 3), (6, 2, 3), (28, 4, 7), (4, 4, 1)])
+def test_decode_fused_rope_and_cache_write_bit_identical(hip, Hq, Hkv, G):
+    """td_qwen2_set_fused_rope: the decode attention rotates its own q heads and the new key, attends the new key / value from registers and
+    writes them to the cache.  Hidden states, logits AND the cache (seen through three further steps) must be bit-identical to the form with
+    the separate rope + scatter launch, for one head per workgroup and for grouped q heads, sequence lengths that put the new key in every
+    key slot of the 16-slot order, and three distinct M-RoPE streams."""
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    tc = Qwen2VLTextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=Hq, num_key_value_heads=Hkv, intermediate_size=1024, vocab_size=1024)
+    lens = [1, 2, 15, 16, 17, 31, 63, 64, 65, 100, 130]
+    outs = {}
+    for fused in (False, True):
+        e = Qwen2VLTextEngine(tc, max_model_len=len(lens) * 160, n_slots=len(lens)).init_random(5)
+        assert e.set_fused_rope(fused) is True        # the default is the fused form
+        g = torch.Generator().manual_seed(9)
+        for b, n in enumerate(lens):
+            e.forward(e.text_position_ids(n), torch.randint(0, 1024, (n,), generator=g).to(torch.int32), slot=b)
+        prev = hip.lib().td_attention_decode_set_group(G)
+        try:
+            cur, steps = list(lens), []
+            for step in range(4):          # step 0 eager, step 1 captures the graph, steps 2-3 replay it
+                toks = torch.randint(0, 1024, (len(lens),), generator=g).tolist()
+                pos = torch.tensor([cur, [c // 2 + 1 for c in cur], [(3 * c) % 7 for c in cur]], dtype=torch.int32)
+                h, lg = e.decode_batch(toks, pos, cur)
+                torch.cuda.synchronize()
+                steps.append((h.clone(), lg.clone()))
+                cur = [c + 1 for c in cur]
+        finally:
+            hip.lib().td_attention_decode_set_group(prev)
+        outs[fused] = steps
+    for (ha, la), (hb, lb) in zip(outs[False], outs[True]):
+        assert torch.isfinite(hb.float()).all() and torch.equal(ha, hb) and torch.equal(la, lb)
+
+
 def test_batched_prefill_in_several_passes(hip):
     """A request batch whose padded prompts exceed the activation workspace (40 x 64 rows against 256) is prefilled four
     sequences per pass into consecutive cache slots (td_qwen2_prefill_batch_at): same states as one request at a time."""

@@ -55,6 +55,43 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
   u32x4_t q[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) q[g] = *(const u32x4_t*)(Qb + (size_t)g * 128);
+  // fused rotary embedding + cache write (TdAttnParams::dec_kv_new): lane j of a 16-lane row holds head dims 8j .. 8j+7; rotate_half pairs dim d with
+  // d +- 64, i.e. lane j with lane j ^ 8 of the same row (one DPP rotate by 8)
+  const bool fused = p.dec_kv_new != nullptr;
+  u32x4_t knew = {0u, 0u, 0u, 0u}, vnew = {0u, 0u, 0u, 0u};
+  if (fused) {
+    float cs[8], sn[8];
+    {
+      const f32x4_t c0 = *(const f32x4_t*)(p.dec_cos + (size_t)b * 128 + 8 * j), c1 = *(const f32x4_t*)(p.dec_cos + (size_t)b * 128 + 8 * j + 4);
+      const f32x4_t s0 = *(const f32x4_t*)(p.dec_sin + (size_t)b * 128 + 8 * j), s1 = *(const f32x4_t*)(p.dec_sin + (size_t)b * 128 + 8 * j + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { cs[i] = c0[i]; cs[4 + i] = c1[i]; sn[i] = s0[i]; sn[4 + i] = s1[i]; }
+    }
+    auto rope = [&](const u32x4_t raw) -> u32x4_t {
+      float x[8], y[8];
+      unsigned r4[4] = {raw[0], raw[1], raw[2], raw[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[2 * i] = bf_lo(r4[i]); x[2 * i + 1] = bf_hi(r4[i]); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[i]), 0x128, 0xf, 0xf, false));      // lane j ^ 8 of the row
+        const float rot = (j < 8) ? -other : other;
+        y[i] = rbf(x[i] * cs[i]) + rbf(rot * sn[i]);
+      }
+      return u32x4_t{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = rope(q[g]);
+    const int KVW = p.Hkv * 2 * 128;
+    knew = rope(*(const u32x4_t*)(p.dec_kv_new + (size_t)b * KVW + (size_t)kvh * 128 + 8 * j));
+    vnew = *(const u32x4_t*)(p.dec_kv_new + (size_t)b * KVW + (size_t)(p.Hkv + kvh) * 128 + 8 * j);
+    if ((qg * G) % p.q_per_kv == 0 && tid < 16) {      // one 16-lane row of the kv head's first workgroup writes the new cache row
+      bf16_t* dst = (bf16_t*)p.K + (size_t)p.dec_row_off[b];
+      *(u32x4_t*)(dst + (size_t)kvh * 128 + 8 * j) = knew;
+      *(u32x4_t*)(dst + (size_t)(p.Hkv + kvh) * 128 + 8 * j) = vnew;
+    }
+  }
+  const int len_cache = fused ? len - 1 : len;      // keys that are read from the cache; with the fused form the last key sits in registers
   float m[G], l[G], o[G][8];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -84,7 +121,7 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
   // The keys of a slot are still visited in increasing order, so the arithmetic -- and the result -- is unchanged.
   constexpr int UN = 4;
   int key = slot;
-  for (; key + 16 * (UN - 1) < len; key += 16 * UN) {
+  for (; key + 16 * (UN - 1) < len_cache; key += 16 * UN) {
     u32x4_t kk[UN], vv[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -94,11 +131,12 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
 #pragma unroll
     for (int u = 0; u < UN; ++u) one_key(kk[u], vv[u]);
   }
-  for (; key < len; key += 16) {
+  for (; key < len_cache; key += 16) {
     const u32x4_t kk = *(const u32x4_t*)(Kb + (size_t)key * p.ldkv);
     const u32x4_t vv = *(const u32x4_t*)(Vb + (size_t)key * p.ldkv);
     one_key(kk, vv);
   }
+  if (fused && key == len - 1) one_key(knew, vnew);      // the slot that owns key len - 1 in the strided order: same arithmetic order as reading it from the cache
   // merge the 4 key slots of this wave (lanes 16 / 32 apart hold the same d-chunk), then the 4 waves through LDS
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -147,6 +185,8 @@ int td_attn_decode_launch(const TdAttnParams& p, hipStream_t stream) {
   TD_CHECK_ARG(p.Sq == 1 && p.head_dim == 128 && p.Hq % p.Hkv == 0, "td_attn_decode: needs Sq = 1, head_dim 128");
   TdAttnParams q = p;
   q.q_per_kv = p.Hq / p.Hkv;
+  if (p.dec_kv_new) TD_CHECK_ARG(p.kv_lens && p.dec_cos && p.dec_sin && p.dec_row_off && ((uintptr_t)p.dec_kv_new | (uintptr_t)p.dec_cos | (uintptr_t)p.dec_sin) % 16 == 0,
+                                 "td_attn_decode: the fused rotary / cache-write form needs kv_lens, both table rows and the cache row offsets");
   TD_CHECK_ARG(p.ldkv % 8 == 0 && ((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) % 16 == 0 && p.q_bstride % 8 == 0 && p.kv_bstride % 8 == 0,
                "td_attn_decode: operands must be 16-byte aligned");
   // G q heads of one kv head per workgroup read its K/V once instead of G times (from L2); taken when the grid still gives

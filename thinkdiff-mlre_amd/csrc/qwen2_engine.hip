@@ -63,6 +63,7 @@ struct td_qwen2 {
   std::unordered_map<int, int> step_calls;      // calls seen per key: the first runs eagerly (one-time function attributes are set outside a capture)
   hipStream_t capture_stream = nullptr;
   bool graphs_ok = true;
+  bool fused_rope = true;                       // decode: rotary embedding + cache write inside the attention launch (td_qwen2_set_fused_rope)
   int *tok_buf = nullptr, *pos_buf = nullptr;   // [MAX_BATCH], [3, MAX_BATCH]: the step's token and position ids
   bf16_t* logits_buf = nullptr;                 // [MAX_BATCH, vocab]
 };
@@ -387,6 +388,14 @@ int td_qwen2_set_slots(td_qwen2* f, int n_slots) {
   return TD_OK;
 }
 
+int td_qwen2_set_fused_rope(td_qwen2* f, int on) {
+  TD_CHECK_ARG(f, "td_qwen2_set_fused_rope: null handle");
+  const int prev = f->fused_rope ? 1 : 0;
+  f->fused_rope = on != 0;
+  drop_step_graphs(f);      // the captured steps carry the old launch list
+  return prev;
+}
+
 int td_qwen2_slot_capacity(const td_qwen2* f) { return f ? f->slot_len : 0; }
 
 int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream) {
@@ -425,8 +434,13 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
       g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
       TDQ_TRY(td_gemm_launch(g, s));
     }
-    hipLaunchKernelGGL(td_decode_rope_scatter_kernel, dim3(B), dim3(256), 0, s, f->q, f->kvtmp, l.kv, row_off, f->cosT, f->sinT, Hq, Hkv);
+    // rotary embedding of the new q / k rows and the cache write ride inside the attention launch (TdAttnParams::dec_kv_new);
+    // td_qwen2_set_fused_rope(f, 0) / TD_QWEN2_NO_FUSED_ROPE: the separate launch (A/B and the bit-identity test)
+    static const bool env_unfused = getenv("TD_QWEN2_NO_FUSED_ROPE") != nullptr;
+    const bool fused_rope = f->fused_rope && !env_unfused;
+    if (!fused_rope) hipLaunchKernelGGL(td_decode_rope_scatter_kernel, dim3(B), dim3(256), 0, s, f->q, f->kvtmp, l.kv, row_off, f->cosT, f->sinT, Hq, Hkv);
     TdAttnParams ap;
+    if (fused_rope) { ap.dec_kv_new = f->kvtmp; ap.dec_cos = f->cosT; ap.dec_sin = f->sinT; ap.dec_row_off = row_off; }
     ap.Q = f->q; ap.ldq = QW; ap.q_bstride = QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW;
     ap.kv_bstride = (long long)f->slot_len * KVW; ap.O = f->attn; ap.ldo = QW; ap.o_bstride = QW;
     ap.batch = B; ap.Sq = 1; ap.Skv = max_len; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f;

@@ -78,6 +78,12 @@ struct TdAttnParams {
   const float* bias = nullptr;
   // optional per-batch cache length (device int[batch], causal kernel): sequence b attends keys [0, kv_lens[b]); Skv = the largest
   const int* kv_lens = nullptr;
+  // decode kernel only (Sq = 1, kv_lens given): the step's rotary embedding and cache write happen INSIDE the attention launch.  Q then holds the RAW
+  // q rows of the projection, dec_kv_new [batch, 2 Hkv 128] the raw new k | v rows, dec_cos / dec_sin fp32 [batch, 128] the tokens' M-RoPE table rows,
+  // dec_row_off int[batch] the element offset of each sequence's new cache row (relative to K).  Every workgroup rotates its q heads and the new key
+  // itself (rotate_half, every product rounded to bf16: td_decode_rope_scatter_kernel's arithmetic), uses the new key / value as the last of its
+  // kv_lens[b] keys from registers, and the first workgroup of each kv head writes them to the cache -- nobody reads that row in this launch.
+  const bf16_t* dec_kv_new = nullptr; const float* dec_cos = nullptr; const float* dec_sin = nullptr; const int* dec_row_off = nullptr;
   // optional packed segments (device int[batch + 1], non-causal): segment b = rows [seg_starts[b], seg_starts[b+1]) of q/k/v/o; Sq = Skv = the longest
   const int* seg_starts = nullptr;
   // optional hand-off workspace of the persistent (stream-K) joint-attention kernel: td_attn_streamk_ws_bytes() bytes, zeroed

@@ -110,6 +110,7 @@ def _declare(L):
         "td_qwen2_embed_tokens": [vp, vp, vp, i32, vp],
         "td_qwen2_forward_slot": [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp],
         "td_qwen2_set_slots": [vp, i32],
+        "td_qwen2_set_fused_rope": [vp, i32],
         "td_qwen2_create_slots": [vp, i32, i32, vp],
         "td_qwen2_create_ex": [vp, i32, i32, i32, vp],
         "td_qwen2_prefill_batch": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],

@@ -128,6 +128,11 @@ class Qwen2VLTextEngine:
         self.n_slots, self.slot_len = int(n_slots), int(self._L.td_qwen2_slot_capacity(self._h))
         return self
 
+    def set_fused_rope(self, on: bool) -> bool:
+        """Decode step: rotary embedding + cache write inside the attention launch (default) or as a launch of their own.  Returns the
+        previous setting."""
+        return bool(self._L.td_qwen2_set_fused_rope(self._h, 1 if on else 0))
+
     def forward(self, position_ids, token_ids=None, inputs_embeds=None, pos0: int = 0, want_hidden=True, want_logits=False, slot: int = 0):
         """position_ids int32 [3,n]; token_ids int32 [n] or inputs_embeds bf16 [n,hidden].  Returns
         (hidden [n,hidden] | None, logits_last [vocab] | None)."""
