@@ -272,3 +272,45 @@ def test_skinny_m_split_output_and_strided_rows(hip):
     _close(y0, ref[:, :n_split])
     _close(y1[:, :N - n_split], torch.nn.functional.silu(ref[:, n_split:].float()).bfloat16())
     assert not y1[:, N - n_split:].any()
+
+
+@pytest.mark.parametrize("M,N,K,cfg,parts", [
+    (256, 1536, 8960, 1, 10), (256, 1536, 8960, 1, -1), (200, 3584, 18944, -1, -1), (65, 1536, 1536, 1, 6), (129, 2048, 1536, 0, 4),
+    (256, 3584, 3584, -1, -1), (100, 512, 4096, 2, 8), (300, 1536, 2048, -1, 2),
+])
+def test_linear_split_k(hip, M, N, K, cfg, parts):
+    """td_linear_splitk_bf16 (TdGemmParams::split_k): K split over workgroups, fp32 partial sums added in index order by a second launch.  The
+    decode shapes of 65..256 sequences (2B: 1536 / 8960, 7B: 3584 / 18944), forced and automatic part counts, every tile config, bias + in-place
+    residual: against fp32 math (the GEMM tolerance), against the unsplit launch (summation order only), and bit-equal between two runs."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    r = torch.randn(M, N, generator=g).bfloat16().cuda()
+    ref = _ref_linear(x.cpu(), w.cpu(), b.cpu(), res=r.cpu())
+    y1 = hip.linear_splitk(x, w, b, res=r, out=r.clone(), split_k=parts, tile_cfg=cfg)          # (in place on a copy of the residual, as the engine does)
+    y2 = hip.linear_splitk(x, w, b, res=r, out=r.clone(), split_k=parts, tile_cfg=cfg)
+    y0 = hip.linear(x, w, b, res=r)
+    torch.cuda.synchronize()
+    _close(y1, ref)
+    assert torch.equal(y1, y2)
+    _close(y1, y0.cpu(), 2.0 ** -7)          # (one bf16 ulp of the largest output where the two summation orders round apart)
+
+
+def test_linear_split_k_two_outputs_and_refusals(hip):
+    """The q | k|v projection of a wide decode step: columns >= n_split go to the second buffer (n_split not a tile multiple: the reduction splits, not
+    the tiles); a part count that does not divide the k-tiles is refused, -1 on a form the reduction does not cover falls back to one launch."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K, ns = 130, 1536 + 512, 1536, 1536
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    q = torch.zeros(M, ns, dtype=torch.bfloat16, device="cuda")
+    kv = torch.zeros(M, N - ns, dtype=torch.bfloat16, device="cuda")
+    hip.linear_splitk(x, w, b, out=q, out1=kv, n_split=ns, split_k=6, tile_cfg=1)
+    torch.cuda.synchronize()
+    ref = _ref_linear(x.cpu(), w.cpu(), b.cpu())
+    _close(q, ref[:, :ns])
+    _close(kv, ref[:, ns:], 2.0 ** -6)
+    with pytest.raises(hip.ThinkDiffHipError):
+        hip.linear_splitk(x, w, b, split_k=5, tile_cfg=1)       # 24 k-tiles are not divisible by 5

@@ -174,6 +174,42 @@ def test_batched_decode_of_forty_sequences(hip):
         assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
 
 
+@pytest.mark.parametrize("B", [65, 150, 256])
+def test_batched_decode_beyond_64_sequences(hip, B):
+    """max_num_seqs = 256 of the precompute job (configs/qwen2_vl_embed_ccsbu.yaml:20): above 64 sequences a decode step runs its Linears on the tile
+    kernels, K split over workgroups for the narrow outputs (TdGemmParams::split_k).  B requests of different lengths, teacher-forced, against
+    generate() per request; the step is also bit-reproducible (graph replay included: steps 0 eager, 1 capture, 2+ replay)."""
+    from thinkdiff.models.qwen2_vl import SamplingParams
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=21)
+    e = _engine(cfg, sd, max_len=256 * 96)
+    g = torch.Generator().manual_seed(8)
+    lens = [3 + (11 * i) % 50 for i in range(B)]
+    gens = [2 + (3 * i) % 5 for i in range(B)]
+    reqs = [{"prompt_token_ids": torch.randint(0, cfg.vocab, (n,), generator=g).tolist()} for n in lens]
+    forced = [torch.randint(0, cfg.vocab, (k,), generator=g).tolist() for k in gens]
+    sp = SamplingParams(max_tokens=6, min_tokens=6, ignore_eos=True)
+    idx = list(range(0, B, max(1, B // 24)))          # a sample of the requests is checked one at a time
+    single = {}
+    for i in idx:
+        o = e.generate(reqs[i]["prompt_token_ids"], sp, forced_output_ids=forced[i])
+        single[i] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
+    e.set_slots(256)
+    assert e.slot_len == 96
+    runs = []
+    for _ in range(2):
+        batch = e.generate_batch(reqs, sp, forced_output_ids=forced)
+        torch.cuda.synchronize()
+        runs.append([{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in batch])
+    for i in idx:
+        a, b = single[i], runs[0][i]
+        assert b["token_ids"] == a["token_ids"] and b["hidden_states"].shape == (gens[i], cfg.hidden)
+        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 5e-3
+        assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a["hidden_states"], b["hidden_states"])
+
+
 @pytest.mark.parametrize("Hq,Hkv,G", [(7, 1, 7), (6, 1, 6), (6, 2, 3), (4, 2, 2), (4, 1, 4)])
 def test_decode_attention_groups_q_heads_of_a_kv_head(hip, Hq, Hkv, G):
     """td_attention_decode_set_group: one workgroup serves G q heads of a kv head (K/V read once).  The batched decode step of a

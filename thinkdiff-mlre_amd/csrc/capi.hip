@@ -42,6 +42,15 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
   return td_gemm_launch(p, (hipStream_t)stream);
 }
 
+int td_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, const void* bias, void* y0, int64_t ldy0, void* y1, int64_t ldy1, int n_split,
+                          int M, int N, int K, const void* res, int64_t ldr, int tile_cfg, int split_k, void* stream) {
+  TdGemmParams p;
+  p.A = (const bf16_t*)x; p.lda = (int)ldx; p.W = (const bf16_t*)w; p.bias = (const bf16_t*)bias;
+  p.C = (bf16_t*)y0; p.ldc = (int)ldy0; p.C2 = (bf16_t*)y1; p.ldc2 = (int)ldy1; p.n_split = y1 ? n_split : 0;
+  p.res = (const bf16_t*)res; p.ldr = (int)ldr; p.M = M; p.N = N; p.K = K; p.cfg = tile_cfg; p.split_k = split_k;
+  return td_gemm_launch(p, (hipStream_t)stream);
+}
+
 int td_linear_grouped2_bf16(const void* x0, int M0, const void* w0, const void* bias0, const void* gate0,
                             const void* res0, void* y0, const void* x1, int M1, const void* w1,
                             const void* bias1, const void* gate1, const void* res1, void* y1,

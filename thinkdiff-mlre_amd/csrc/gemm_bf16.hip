@@ -17,8 +17,11 @@
 //    stores are full 128-B lines per row, with no LDS round trip.
 //  * blockIdx -> tile mapping is XCD-aware (bijective remap + grouped M ordering) so the 32
 //    tiles resident on one XCD share A/W panels through that XCD's L2.
+#include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "td_common.h"
 #include "td_kernels.h"
@@ -280,12 +283,15 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
 
   const bf16_t* Aptr = second_prob ? p.g_A : p.A;
   const bf16_t* Wptr = second_prob ? p.g_W : p.W;
+  const int part = p.k_parts > 1 ? (int)blockIdx.y : 0;      // split-K launches (bf16, one problem): this workgroup contracts K-range `part`
+  if (p.k_parts > 1) { Aptr += (size_t)part * p.K; Wptr += (size_t)part * p.K; }
   ProbView pv;
   pv.bias = second_prob ? p.g_bias : p.bias;
   pv.gate = second_prob ? p.g_gate : p.gate;
   pv.res = second_prob ? p.g_res : p.res;
   pv.C = second_prob ? p.g_C : p.C;
   pv.M = second_prob ? p.g_M : p.M;
+  if (p.k_parts > 1) pv.C = (bf16_t*)((float*)p.C + (size_t)part * p.M * p.ldc);      // (out_f32: its slab of the fp32 partial sums)
   pv.q8 = second_prob ? p.g_q8 : p.q8; pv.q8_inv = second_prob ? p.g_q8_inv : p.q8_inv; pv.q8_amax = second_prob ? p.g_q8_amax : p.q8_amax;
   pv.q8_smooth = second_prob ? p.g_q8_smooth : p.q8_smooth;
   if (m0 >= pv.M) return;      // (a sub-tile of a split tail tile that lies wholly below the problem's last row; workgroup-uniform)
@@ -293,7 +299,7 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
   // ---- buffer descriptors (wave-uniform; OOB rows read as zero) -----------------------------
   const unsigned bytesA = CONV ? (unsigned)((long long)(p.conv_H >> p.conv_up) * (p.conv_W >> p.conv_up) * p.conv_Cin * 2)
                                 : (unsigned)(((long long)(pv.M - 1) * p.lda + p.K) * ESZ);
-  const unsigned bytesW = (unsigned)((long long)p.N * p.K * ESZ);
+  const unsigned bytesW = (unsigned)((((long long)p.N - 1) * p.ldw + p.K) * ESZ);
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Aptr, 0, bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wptr, 0, bytesW, 0x00020000);
 
@@ -324,7 +330,7 @@ __device__ __forceinline__ void gemm_tile(const TdGemmParams& p, char* smem, con
     const int rem = rho - wcol * (16 * WN);
     const int j = rem >> 4, i16 = rem & 15;
     const int n = n0 + wcol * (16 * WN) + (i16 >> 2) * NV + j * 4 + (i16 & 3);
-    voffS[SA + s] = (unsigned)n * (unsigned)p.K * ESZ + schunk;
+    voffS[SA + s] = (unsigned)n * (unsigned)p.ldw * ESZ + schunk;
     ldsS[SA + s] = g * 1024;
   }
   // Implicit-GEMM 3x3 convolution (CONV): A is an NHWC image [Hin*Win, Cin]; k-tile kt covers tap kt / (Cin/64)
@@ -727,7 +733,7 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
   if (p.C2) TD_CHECK_ARG(p.n_split % BN == 0, "td_gemm: n_split=%d must be a multiple of the N tile %d", p.n_split, BN);
   int grid = p.tiles_m * p.tiles_n;
   if constexpr (TAIL == 1 && WM == 8 && WN == 4 && !CONV) {      // the 256 x 256 tile of the block Linears: see whether its last round is worth cutting up
-    const int s = p.no_tail ? 1 : tail_split(grid, cu_count());
+    const int s = (p.no_tail || p.k_parts > 1) ? 1 : tail_split(grid, cu_count());
     if (s == 2) return launch_cfg<WM, WN, CONV, FP8, I8, 2>(p0, stream);
     if (s == 4) return launch_cfg<WM, WN, CONV, FP8, I8, 4>(p0, stream);
   }
@@ -745,9 +751,78 @@ int launch_cfg(const TdGemmParams& p0, hipStream_t stream) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
   }
-  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL>), dim3(grid), dim3(512), LDS, stream, p);
+  if (p.ldw == 0) p.ldw = p.K;
+  hipLaunchKernelGGL((td_gemm_bf16_nt_kernel<WM, WN, CONV, FP8, I8, TAIL>), dim3(grid, p.k_parts > 1 ? p.k_parts : 1), dim3(512), LDS, stream, p);
   TD_CHECK_LAUNCH();
   return 0;
+}
+
+}  // namespace
+
+// ---- K split over workgroups (TdGemmParams::split_k) --------------------------------------------------------------------------
+// Second launch of a split GEMM: out[m, n] = epilogue(sum over parts, in index order, of the fp32 partial sums) with the tile kernel's rounding
+// points (Linear output + bias; a residual is added to the bf16-rounded output; the final pack rounds).  4 columns per thread.
+__global__ __launch_bounds__(256) void td_gemm_splitk_reduce_kernel(const float* __restrict__ ws, const int parts, const int M, const int N, const bf16_t* bias,
+                                                                    const bf16_t* res, const int ldr, bf16_t* C, const int ldc, bf16_t* C2, const int ldc2, const int n_split) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (idx >= (long long)M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx - (long long)m * n4) * 4;
+  const size_t slab = (size_t)M * N;
+  const float* src = ws + (size_t)m * N + n;
+  f32x4_t v = *(const f32x4_t*)src;
+  for (int k = 1; k < parts; ++k) v += *(const f32x4_t*)(src + (size_t)k * slab);
+  if (bias) {
+    const u32x2_t b = *(const u32x2_t*)(bias + n);
+    v += f32x4_t{bf_lo(b[0]), bf_hi(b[0]), bf_lo(b[1]), bf_hi(b[1])};
+  }
+  if (res) {
+    const u32x2_t r = *(const u32x2_t*)(res + (size_t)m * ldr + n);
+    v = f32x4_t{rbf(v[0]) + bf_lo(r[0]), rbf(v[1]) + bf_hi(r[0]), rbf(v[2]) + bf_lo(r[1]), rbf(v[3]) + bf_hi(r[1])};
+  }
+  const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  if (C2 && n >= n_split) *(u32x2_t*)(C2 + (size_t)m * ldc2 + (n - n_split)) = o;
+  else *(u32x2_t*)(C + (size_t)m * ldc + n) = o;
+}
+
+namespace {
+
+constexpr long long SPLITK_POOL_BYTES = 64ll << 20;
+
+// one pooled buffer of partial sums per (device, stream): launches on one stream never overlap
+int gemm_splitk_pool(hipStream_t stream, float** out) {
+  struct Entry { int dev; hipStream_t stream; float* ws; };
+  static std::mutex mu;
+  static std::vector<Entry> pool;
+  int dev = 0;
+  TD_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& e : pool)
+    if (e.dev == dev && e.stream == stream) { *out = e.ws; return 0; }
+  float* w = nullptr;
+  TD_CHECK_HIP(hipMalloc((void**)&w, (size_t)SPLITK_POOL_BYTES));
+  pool.push_back(Entry{dev, stream, w});
+  *out = w;
+  return 0;
+}
+
+// Parts of a split launch, or 1.  Under -1: as many as spread tiles x parts over the CUs, at most 16, at least 4 k-tiles each, a divisor of the
+// k-tile count, partial sums inside the workspace.
+int plan_split_k(const TdGemmParams& p, int cfg) {
+  if (p.split_k == 0 || p.split_k == 1) return 1;
+  const bool covered = !p.fp8 && !p.i8 && p.conv_H == 0 && p.g_M == 0 && !p.out_f32 && p.act == TD_ACT_NONE && p.act2 == TD_ACT_NONE && !p.gate && !p.q8 && !p.glu_I;
+  if (!covered) return 1;
+  static const int bm[4] = {256, 256, 32, 288}, bn[4] = {256, 64, 256, 192};
+  const long long tiles = (long long)((p.M + bm[cfg] - 1) / bm[cfg]) * ((p.N + bn[cfg] - 1) / bn[cfg]);
+  const int ktiles = p.K / 64;
+  const long long cap = p.sk_ws ? p.sk_ws_bytes : SPLITK_POOL_BYTES;
+  const long long by_ws = cap / ((long long)p.M * p.N * 4);
+  if (p.split_k > 1) return (ktiles % p.split_k == 0 && p.split_k <= by_ws) ? p.split_k : 1;      // (1 is then refused by the caller)
+  int limit = (int)std::min<long long>(std::min<long long>(16, cu_count() / std::max<long long>(tiles, 1)), ktiles / 4);
+  limit = (int)std::min<long long>(limit, by_ws);
+  for (int d = limit; d >= 2; --d)
+    if (ktiles % d == 0) return d;
+  return 1;
 }
 
 }  // namespace
@@ -803,6 +878,28 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   }
   if (p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
   const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
+  if (const int parts = plan_split_k(p, cfg); parts > 1) {
+    float* ws = p.sk_ws;
+    if (!ws) {
+      if (int rc = gemm_splitk_pool(stream, &ws)) return rc;
+    }
+    TdGemmParams q = p;
+    q.split_k = 0; q.k_parts = parts; q.K = p.K / parts; q.ldw = p.K;
+    q.C = (bf16_t*)ws; q.ldc = p.N; q.out_f32 = 1; q.bias = nullptr; q.res = nullptr; q.C2 = nullptr; q.n_split = 0;
+    int rc;
+    switch (cfg) {
+      case 1: rc = launch_cfg<8, 1>(q, stream); break;
+      case 2: rc = launch_cfg<1, 4>(q, stream); break;
+      case 3: rc = launch_cfg<9, 3>(q, stream); break;
+      default: rc = launch_cfg<8, 4>(q, stream);
+    }
+    if (rc) return rc;
+    TD_GRID_1D(nblk, (long long)p.M * (p.N / 4), 256, "td_gemm(split-K reduce)");
+    hipLaunchKernelGGL(td_gemm_splitk_reduce_kernel, dim3(nblk), dim3(256), 0, stream, ws, parts, p.M, p.N, p.bias, p.res, p.ldr, p.C, p.ldc, p.C2, p.ldc2, p.n_split);
+    TD_CHECK_LAUNCH();
+    return 0;
+  }
+  TD_CHECK_ARG(p.split_k <= 1, "td_gemm: split_k=%d is not available for this problem (bf16 plain / bias / residual forms whose k-tile count it divides)", p.split_k);
   if (p.q8) {
     TD_CHECK_ARG(p.i8 && p.q8_inv && p.q8_amax && p.ldq8 % 16 == 0 && ((uintptr_t)p.q8) % 16 == 0 && (p.g_M == 0 || (p.g_q8 && p.g_q8_inv && p.g_q8_amax)),
                  "td_gemm(q8 output): int8 kernels only; needs the per-row inverse scales, the amax accumulators and 16-byte aligned rows");

@@ -66,6 +66,7 @@ struct td_qwen2 {
   bool fused_rope = true;                       // decode: rotary embedding + cache write inside the attention launch (td_qwen2_set_fused_rope)
   int *tok_buf = nullptr, *pos_buf = nullptr;   // [MAX_BATCH], [3, MAX_BATCH]: the step's token and position ids
   bf16_t* logits_buf = nullptr;                 // [MAX_BATCH, vocab]
+  float* sk_ws = nullptr;                       // partial sums of the decode step's split-K Linears (65-256 sequences): the engine's own buffer, so a captured step allocates nothing
 };
 
 namespace {
@@ -75,7 +76,12 @@ void q_add(td_qwen2* f, const std::string& name, bf16_t* p, int64_t n) {
   f->slots.push_back({name, p, n});
 }
 
-constexpr int MAX_BATCH = 64;   // td_gemv_mfma_kernel streams the weights once for up to 64 rows
+// Sequences per decode step (vLLM's max_num_seqs of the precompute job is 256: configs/qwen2_vl_embed_ccsbu.yaml:20).  Up to 64 the Linears of a step
+// are weight streams (td_gemv_mfma_kernel: one pass over the weights for up to 64 rows); above, the step is a small-M GEMM problem and takes the tile
+// kernels the prefill uses, with K split over workgroups where the output is narrow (td_gemm_launch's split_k form).
+constexpr int MAX_BATCH = 256;
+constexpr int STREAM_BATCH = 64;
+constexpr int64_t SK_WS_BYTES = 32ll << 20;
 
 struct IntPack { int v[2 * MAX_BATCH]; };
 __global__ void td_set_ints_kernel(int* dst, IntPack vals, int n) {
@@ -211,6 +217,7 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
       {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
       {(void**)&f->kvtmp, n * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4}, {(void**)&f->lastrows, (int64_t)MAX_BATCH * D * 2},
       {(void**)&f->tok_buf, MAX_BATCH * 4}, {(void**)&f->pos_buf, 3 * MAX_BATCH * 4}, {(void**)&f->logits_buf, (int64_t)MAX_BATCH * cfg->vocab * 2},
+      {(void**)&f->sk_ws, SK_WS_BYTES},
   };
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
@@ -419,6 +426,7 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
   const int* kv_lens = f->ibuf;
   const int* row_off = f->ibuf + MAX_BATCH;
+  const bool wide = B > STREAM_BATCH;
 
   TDQ_TRY(td_embed_gather_launch(f->tok_buf, f->embed_w, f->h, B, D, f->cfg.vocab, s));
   TDQ_TRY(td_mrope_table_launch(f->pos_buf, B, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
@@ -432,7 +440,18 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
       TdGemmParams g;
       g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = B; g.N = QW + KVW; g.K = D;
       g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
-      TDQ_TRY(td_gemm_launch(g, s));
+      if (!wide) {
+        TDQ_TRY(td_gemm_launch(g, s));
+      } else if (QW % 256 == 0) {      // (the column split needs a tile width that divides 256: as the prefill)
+        g.cfg = td_gemm_config_id(B, QW + KVW, D) == 1 ? 1 : 0;
+        g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES;
+        TDQ_TRY(td_gemm_launch(g, s));
+      } else {
+        TdGemmParams a = g; a.C2 = nullptr; a.N = QW; a.split_k = -1; a.sk_ws = f->sk_ws; a.sk_ws_bytes = SK_WS_BYTES;
+        TDQ_TRY(td_gemm_launch(a, s));
+        TdGemmParams b2 = g; b2.C2 = nullptr; b2.W = l.qkv_w + (size_t)QW * D; b2.bias = l.qkv_b + QW; b2.N = KVW; b2.C = f->kvtmp; b2.ldc = KVW; b2.split_k = -1; b2.sk_ws = f->sk_ws; b2.sk_ws_bytes = SK_WS_BYTES;
+        TDQ_TRY(td_gemm_launch(b2, s));
+      }
     }
     // rotary embedding of the new q / k rows and the cache write ride inside the attention launch (TdAttnParams::dec_kv_new);
     // td_qwen2_set_fused_rope(f, 0) / TD_QWEN2_NO_FUSED_ROPE: the separate launch (A/B and the bit-identity test)
@@ -449,16 +468,24 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
     {
       TdGemmParams g;
       g.A = f->attn; g.lda = QW; g.W = l.o_w; g.C = f->h; g.ldc = D; g.res = f->h; g.ldr = D; g.M = B; g.N = D; g.K = QW;
+      if (wide) { g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES; }
       TDQ_TRY(td_gemm_launch(g, s));
     }
     np.w = l.ln2_w;
     TDQ_TRY(td_norm_rows_launch(np, s));
     {
       TdGemmParams g;
-      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->act; g.ldc = I; g.M = B; g.N = I; g.K = D; g.glu_I = I;   // gate | up, SiLU and product in one pass
-      TDQ_TRY(td_gemm_launch(g, s));
+      if (!wide) {
+        g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->act; g.ldc = I; g.M = B; g.N = I; g.K = D; g.glu_I = I;   // gate | up, SiLU and product in one pass
+        TDQ_TRY(td_gemm_launch(g, s));
+      } else {      // the prefill's form: gate | up as one Linear, SiLU and product in a pass of their own (the same rounding points)
+        g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = B; g.N = 2 * I; g.K = D;
+        TDQ_TRY(td_gemm_launch(g, s));
+        TDQ_TRY(td_silu_mul_launch(f->gu, f->act, B, I, s));
+      }
       TdGemmParams d;
       d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = B; d.N = D; d.K = I;
+      if (wide) { d.split_k = -1; d.sk_ws = f->sk_ws; d.sk_ws_bytes = SK_WS_BYTES; }
       TDQ_TRY(td_gemm_launch(d, s));
     }
   }
@@ -476,7 +503,7 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
 
 extern "C" {
 
-// One new token for each of the sequences in slots 0 .. B-1 (B <= 64): token_ids int32[B], position_ids int32[3,B] (device),
+// One new token for each of the sequences in slots 0 .. B-1 (B <= 256): token_ids int32[B], position_ids int32[3,B] (device),
 // cache_pos[b] = tokens already in slot b (HOST ints).  hidden_out bf16[B,hidden], logits bf16[B,vocab] (either may be NULL).
 int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
                           void* hidden_out, void* logits, void* stream) {
@@ -485,6 +512,7 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
   hipStream_t s = (hipStream_t)stream;
   const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
+  TD_CHECK_ARG((long long)B * f->slot_len * KVW < (1ll << 31), "td_qwen2_decode_batch: %d slots of %d rows exceed the 32-bit cache row offsets", B, f->slot_len);
   IntPack ip;
   int max_len = 0;
   for (int b = 0; b < B; ++b) {

@@ -23,6 +23,15 @@ struct TdGemmParams {
   const bf16_t* g_gate = nullptr; const bf16_t* g_res = nullptr; bf16_t* g_C = nullptr;
   int g_M = 0;
   int cfg = -1;                  // tile config override (-1: auto), see td_gemm_config_id
+  // K split over workgroups (tile kernels, bf16 operands, plain / bias / residual / split-output epilogues): few output tiles and a long K -- the
+  // KV-cached decode of 65-256 sequences, M <= 256 against N = hidden -- leave most CUs without a workgroup.  split_k = -1: the launcher decides
+  // (parts so that tiles x parts covers the CUs, every part a whole number of k-tiles); > 1: that many parts; 0 / 1: none.  Part j contracts
+  // K-range j of every tile into fp32 partial sums in sk_ws ([parts][M][N] floats; null: a pooled buffer of the (device, stream)), and a second launch
+  // adds the parts in index order -- the result does not depend on the order the workgroups ran in -- and applies the epilogue with the tile
+  // kernel's rounding points.  Forms the reduction does not cover (activation, gate, int8 / fp8, conv, grouped) are launched unsplit under -1.
+  int split_k = 0;
+  float* sk_ws = nullptr; long long sk_ws_bytes = 0;
+  int ldw = 0, k_parts = 1;      // filled by the launcher: row stride of W in elements (= the whole K), parts of a split launch (K = ONE part's extent)
   int out_f32 = 0;               // C is float* (ldc in floats): acc + bias stored unrounded, no act/gate/res
   // implicit-GEMM 3x3 convolution over an NHWC image (conv_H > 0): A = input [Hin*Win, Cin], W = [N, 9*Cin]
   // (k = tap*Cin + c, tap = ky*3+kx), M = conv_H*conv_W output pixels; conv_up = 1 fuses a nearest 2x upsample

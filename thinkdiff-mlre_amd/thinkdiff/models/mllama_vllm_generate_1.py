@@ -31,7 +31,7 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         vc = dict(vllm_config or {})
         self.config = SimpleNamespace(vllm_config=vc, text_input_key=text_input_key)
         self._device = torch.device(device)
-        # vLLM decodes `max_num_seqs` requests together; here up to 64 sequences share each pass over the weights
+        # vLLM decodes `max_num_seqs` requests together (256 in configs/qwen2_vl_embed_ccsbu.yaml); the engine takes up to 256 per decode step
         self.decode_batch = max(1, min(Qwen2VLTextEngine.MAX_BATCH, int(vc.get("max_num_seqs", Qwen2VLTextEngine.MAX_BATCH))))
         self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch,
                                         prefill_rows=min(int(vc.get("max_num_batched_tokens", 16384)), 16384) if self.decode_batch > 1 else None)

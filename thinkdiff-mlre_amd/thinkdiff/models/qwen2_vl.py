@@ -263,12 +263,12 @@ class Qwen2VLTextEngine:
         dev = generator.device if generator is not None else "cpu"
         return int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=dev))
 
-    MAX_BATCH = 64      # td_qwen2_decode_batch: sequences sharing one pass over the weights
+    MAX_BATCH = 256     # td_qwen2_decode_batch: sequences sharing one decode step (vLLM's max_num_seqs of the precompute job)
 
     @torch.no_grad()
     def generate_batch(self, requests: Sequence[dict], sampling: SamplingParams, eos_token_id: Optional[int] = None,
                        generator: Optional[torch.Generator] = None, forced_output_ids: Optional[Sequence[Sequence[int]]] = None):
-        """`generate` for up to min(64, n_slots) requests together: each prompt is prefilled into its own cache slot, then
+        """`generate` for up to min(256, n_slots) requests together: each prompt is prefilled into its own cache slot, then
         every decode step advances all unfinished sequences in one pass over the weights (what vLLM's batching gives the
         reference's precompute job).  requests: dicts with "prompt_token_ids" and optional "position_ids" / "inputs_embeds".
         Returns one generate()-style dict per request, in order."""
