@@ -51,9 +51,13 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
  * sequences (vLLM's max_num_seqs = 256, configs/qwen2_vl_embed_ccsbu.yaml:20: M <= 256 rows against N = hidden columns) -- would leave most CUs
  * idle.  split_k = -1: the launcher picks the parts (1 = an ordinary launch when a split does not pay), > 1: that many (must divide K / 64);
  * the parts' fp32 sums are added in index order by a second launch, so the result does not depend on scheduling.  y1 != NULL: columns >= n_split
- * go to y1 (n_split % 8 == 0).  M > 64 (smaller M is the weight-stream kernel's, which splits K itself).  tile_cfg as td_linear_grouped2_bf16. */
+ * go to y1 (n_split % 8 == 0).  M > 64 (smaller M is the weight-stream kernel's, which splits K itself).  tile_cfg as td_linear_grouped2_bf16
+ * (4 = 256x128).  norm_w != NULL (split_k = -1, no y1, N % 512 == 0, N <= 4096): the reduction launch also writes norm_out[M, ld_norm] =
+ * Qwen2RMSNorm(y0; norm_w, norm_eps) of each finished row, bit-identical to td_norm_rows_bf16 on y0 -- the decoder's o_proj -> post_attention_layernorm
+ * and down_proj -> next input_layernorm pairs ([ext] transformers modeling_qwen2_vl.py Qwen2VLDecoderLayer.forward) as one Linear call. */
 int td_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, const void* bias, void* y0, int64_t ldy0, void* y1, int64_t ldy1, int n_split,
-                          int M, int N, int K, const void* res, int64_t ldr, int tile_cfg, int split_k, void* stream);
+                          int M, int N, int K, const void* res, int64_t ldr, int tile_cfg, int split_k,
+                          const void* norm_w, void* norm_out, int64_t ld_norm, float norm_eps, void* stream);
 
 /* Two Linear problems in ONE launch (same N, K, strides, activation; own rows, weights, bias, gate,
  * residual): FluxTransformerBlock applies each projection to the image stream and to the text stream

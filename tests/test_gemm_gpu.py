@@ -314,3 +314,21 @@ def test_linear_split_k_two_outputs_and_refusals(hip):
     _close(kv, ref[:, ns:], 2.0 ** -6)
     with pytest.raises(hip.ThinkDiffHipError):
         hip.linear_splitk(x, w, b, split_k=5, tile_cfg=1)       # 24 k-tiles are not divisible by 5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1536, 8960), (200, 3584, 3584), (65, 512, 1024), (130, 4096, 512)])
+def test_linear_split_k_with_fused_rmsnorm(hip, M, N, K):
+    """norm_w of td_linear_splitk_bf16: the reduction launch also writes Qwen2RMSNorm of each finished row.  Both outputs bit-equal to the split
+    Linear followed by td_norm_rows_bf16 (same summation order and rounding points), whether the planner splits K or not."""
+    g = torch.Generator().manual_seed(M * 3 + N)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    r = torch.randn(M, N, generator=g).bfloat16().cuda()
+    nw = (1.0 + 0.1 * torch.randn(N, generator=g)).bfloat16().cuda()
+    y0 = hip.linear_splitk(x, w, None, res=r, out=r.clone())
+    n0 = hip.norm_rows(y0, rms=True, eps=1e-6, w=nw)
+    n1 = torch.empty_like(y0)
+    y1 = hip.linear_splitk(x, w, None, res=r, out=r.clone(), norm_w=nw, norm_out=n1, norm_eps=1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(n0, n1)
+    _close(y1, _ref_linear(x.cpu(), w.cpu(), res=r.cpu()))

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
     knew = rope(*(const u32x4_t*)(p.dec_kv_new + (size_t)b * KVW + (size_t)kvh * 128 + 8 * j));
     vnew = *(const u32x4_t*)(p.dec_kv_new + (size_t)b * KVW + (size_t)(p.Hkv + kvh) * 128 + 8 * j);
     if ((qg * G) % p.q_per_kv == 0 && tid < 16) {      // one 16-lane row of the kv head's first workgroup writes the new cache row
-      bf16_t* dst = (bf16_t*)p.K + (size_t)p.dec_row_off[b];
+      bf16_t* dst = (bf16_t*)p.K + (size_t)p.dec_row_off[b] * p.ldkv;      // (a ROW index: 256 sequences x 8192 rows x 1024 elements pass 2^31)
       *(u32x4_t*)(dst + (size_t)kvh * 128 + 8 * j) = knew;
       *(u32x4_t*)(dst + (size_t)(p.Hkv + kvh) * 128 + 8 * j) = vnew;
     }

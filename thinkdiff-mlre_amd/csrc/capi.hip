@@ -43,8 +43,10 @@ int td_linear_split_bf16(const void* x, int64_t ldx, const void* w, const void* 
 }
 
 int td_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, const void* bias, void* y0, int64_t ldy0, void* y1, int64_t ldy1, int n_split,
-                          int M, int N, int K, const void* res, int64_t ldr, int tile_cfg, int split_k, void* stream) {
+                          int M, int N, int K, const void* res, int64_t ldr, int tile_cfg, int split_k,
+                          const void* norm_w, void* norm_out, int64_t ld_norm, float norm_eps, void* stream) {
   TdGemmParams p;
+  p.sk_norm_w = (const bf16_t*)norm_w; p.sk_norm_out = (bf16_t*)norm_out; p.sk_norm_ld = (int)ld_norm; p.sk_norm_eps = norm_eps;
   p.A = (const bf16_t*)x; p.lda = (int)ldx; p.W = (const bf16_t*)w; p.bias = (const bf16_t*)bias;
   p.C = (bf16_t*)y0; p.ldc = (int)ldy0; p.C2 = (bf16_t*)y1; p.ldc2 = (int)ldy1; p.n_split = y1 ? n_split : 0;
   p.res = (const bf16_t*)res; p.ldr = (int)ldr; p.M = M; p.N = N; p.K = K; p.cfg = tile_cfg; p.split_k = split_k;

@@ -785,6 +785,61 @@ __global__ __launch_bounds__(256) void td_gemm_splitk_reduce_kernel(const float*
   else *(u32x2_t*)(C + (size_t)m * ldc + n) = o;
 }
 
+// The same reduction, one wave per row, followed by the RMSNorm of the row it has just finished (TdGemmParams::sk_norm_w).  Lane l owns columns
+// 512 c + 8 l .. + 7 of chunk c -- td_norm_rows_kernel's map -- and the sum of squares is taken in that kernel's order, so the normalised row is
+// bit-identical to the one the separate norm launch would have produced from the bf16 row written here.
+template <int NCH>
+__global__ __launch_bounds__(256) void td_gemm_splitk_reduce_norm_kernel(const float* __restrict__ ws, const int parts, const int M, const bf16_t* bias, const bf16_t* res,
+                                                                         const int ldr, bf16_t* C, const int ldc, const bf16_t* nw, bf16_t* nout, const int nld, const float eps) {
+  constexpr int N = NCH * 512;
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const size_t slab = (size_t)M * N;
+  float x[NCH][8];
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int n = c * 512 + lane * 8;
+    const float* src = ws + (size_t)m * N + n;
+    f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+    for (int k = 1; k < parts; ++k) { a += *(const f32x4_t*)(src + (size_t)k * slab); b += *(const f32x4_t*)(src + (size_t)k * slab + 4); }
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (bias) {
+      const u32x4_t bb = *(const u32x4_t*)(bias + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] += bf_lo(bb[i]); v[2 * i + 1] += bf_hi(bb[i]); }
+    }
+    if (res) {
+      const u32x4_t r = *(const u32x4_t*)(res + (size_t)m * ldr + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] = rbf(v[2 * i]) + bf_lo(r[i]); v[2 * i + 1] = rbf(v[2 * i + 1]) + bf_hi(r[i]); }
+    }
+    const u32x4_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    *(u32x4_t*)(C + (size_t)m * ldc + n) = o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[c][2 * i] = bf_lo(o[i]); x[c][2 * i + 1] = bf_hi(o[i]); }
+  }
+  // td_norm_rows_kernel, rms form: the squares are added chunk by chunk, element by element, then across the wave
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sq += x[c][i] * x[c][i];
+  const float rstd = rsqrtf(wave_sum(sq) * (1.0f / N) + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int n = c * 512 + lane * 8;
+    const u32x4_t wr = *(const u32x4_t*)(nw + n);
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y[2 * i] = rbf(rbf(x[c][2 * i] * rstd) * bf_lo(wr[i]));
+      y[2 * i + 1] = rbf(rbf(x[c][2 * i + 1] * rstd) * bf_hi(wr[i]));
+    }
+    *(u32x4_t*)(nout + (size_t)m * nld + n) = u32x4_t{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
+  }
+}
+
 namespace {
 
 constexpr long long SPLITK_POOL_BYTES = 64ll << 20;
@@ -812,7 +867,7 @@ int plan_split_k(const TdGemmParams& p, int cfg) {
   if (p.split_k == 0 || p.split_k == 1) return 1;
   const bool covered = !p.fp8 && !p.i8 && p.conv_H == 0 && p.g_M == 0 && !p.out_f32 && p.act == TD_ACT_NONE && p.act2 == TD_ACT_NONE && !p.gate && !p.q8 && !p.glu_I;
   if (!covered) return 1;
-  static const int bm[4] = {256, 256, 32, 288}, bn[4] = {256, 64, 256, 192};
+  static const int bm[5] = {256, 256, 32, 288, 256}, bn[5] = {256, 64, 256, 192, 128};
   const long long tiles = (long long)((p.M + bm[cfg] - 1) / bm[cfg]) * ((p.N + bn[cfg] - 1) / bn[cfg]);
   const int ktiles = p.K / 64;
   const long long cap = p.sk_ws ? p.sk_ws_bytes : SPLITK_POOL_BYTES;
@@ -825,9 +880,31 @@ int plan_split_k(const TdGemmParams& p, int cfg) {
   return 1;
 }
 
+// 64 < M <= 256 with nothing forced (the decode step of 65-256 sequences: every Linear is one row of tiles): tile width and parts are chosen
+// TOGETHER from a cost model of the launch -- rounds of the CUs x (k-tiles per part x the tile's k-tile time + a fixed part) + the reduction's
+// traffic -- over the 64-, 128- and 256-column tiles.  What it fixes: the 2B decoder's gate | up (N = 17 920) is 280 tiles of 64 columns, 1.09
+// rounds of 256 CUs, i.e. two (55 us); as 140 tiles of 128 columns it is one.  Microseconds per k-tile measured on the decode shapes (rocprofv3).
+struct WidePlan { int cfg, parts; };
+WidePlan plan_wide(const TdGemmParams& p) {
+  static const int cfgs[3] = {1, 4, 0}, bns[3] = {64, 128, 256};
+  static const double ck[3] = {0.45, 0.6, 1.1};
+  const int cus = cu_count(), ktiles = p.K / 64;
+  WidePlan best{td_gemm_config_id(p.M, p.N, p.K), 1};
+  double best_cost = 1e30;
+  for (int i = 0; i < 3; ++i) {
+    const int parts = plan_split_k(p, cfgs[i]);
+    if (parts == 1 && p.C2 && p.n_split % bns[i] != 0) continue;
+    const long long wgs = (long long)((p.N + bns[i] - 1) / bns[i]) * parts;
+    const double rounds = (double)((wgs + cus - 1) / cus);
+    const double cost = rounds * ((double)(ktiles / parts) * ck[i] + 3.0) + (parts > 1 ? 4.0 + (parts + 0.5) * (double)p.M * p.N * 4.0 / 3.0e6 : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = WidePlan{cfgs[i], parts}; }
+  }
+  return best;
+}
+
 }  // namespace
 
-// Tile choice.  0: 256x256, 1: 256x64 (also: few-tile problems), 2: 32x256, 3: 288x192.  Measured on MI355X (in-process A/B,
+// Tile choice.  0: 256x256, 1: 256x64 (also: few-tile problems), 2: 32x256, 3: 288x192 (4: 256x128, the wide-decode planner's and by request only).  Measured on MI355X (in-process A/B,
 // tools/bench_ops.py gemmcfg): 256x256 wins whenever the grid spans several rounds of the 256 CUs; the
 // 288x192 tile wins where 256x256 leaves a single ragged round (N = 3072 at M = 4289: 204 tiles, but 240
 // tiles of the smaller shape) and K is long enough to amortise its prologue.
@@ -877,8 +954,22 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     return td_gemv_launch(p, stream);
   }
   if (p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
-  const int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
-  if (const int parts = plan_split_k(p, cfg); parts > 1) {
+  int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
+  int parts = 1;
+  if (p.split_k == -1 && p.cfg < 0 && p.M > 64 && p.M <= 256 && !p.fp8 && !p.i8 && p.g_M == 0 && !p.out_f32 && !p.q8) {
+    const WidePlan w = plan_wide(p);
+    cfg = w.cfg; parts = w.parts;
+  } else {
+    parts = plan_split_k(p, cfg);
+  }
+  const bool fuse_norm = p.sk_norm_w != nullptr;
+  if (fuse_norm) {
+    TD_CHECK_ARG(p.split_k == -1 && p.sk_norm_out && !p.C2 && p.N % 512 == 0 && p.N <= 4096 && p.sk_norm_ld % 8 == 0 && plan_split_k(p, cfg) >= 1 && !p.fp8 && !p.i8 &&
+                     p.conv_H == 0 && p.g_M == 0 && !p.out_f32 && p.act == TD_ACT_NONE && !p.gate && !p.q8 && p.M > 64 &&
+                     (long long)p.M * p.N * 4 <= (p.sk_ws ? p.sk_ws_bytes : SPLITK_POOL_BYTES),
+                 "td_gemm(sk_norm): plain / bias / residual bf16 launches under split_k = -1, N %% 512 == 0, N <= 4096, M > 64");
+  }
+  if (parts > 1 || fuse_norm) {
     float* ws = p.sk_ws;
     if (!ws) {
       if (int rc = gemm_splitk_pool(stream, &ws)) return rc;
@@ -891,15 +982,26 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
       case 1: rc = launch_cfg<8, 1>(q, stream); break;
       case 2: rc = launch_cfg<1, 4>(q, stream); break;
       case 3: rc = launch_cfg<9, 3>(q, stream); break;
+      case 4: rc = launch_cfg<8, 2>(q, stream); break;
       default: rc = launch_cfg<8, 4>(q, stream);
     }
     if (rc) return rc;
+    if (fuse_norm) {
+      const dim3 g((p.M + 3) / 4), b(256);
+      switch (p.N / 512) {
+#define TD_CASE(n) case n: hipLaunchKernelGGL(td_gemm_splitk_reduce_norm_kernel<n>, g, b, 0, stream, ws, parts, p.M, p.bias, p.res, p.ldr, p.C, p.ldc, p.sk_norm_w, p.sk_norm_out, p.sk_norm_ld, p.sk_norm_eps); break;
+        TD_CASE(1) TD_CASE(2) TD_CASE(3) TD_CASE(4) TD_CASE(5) TD_CASE(6) TD_CASE(7) TD_CASE(8)
+#undef TD_CASE
+      }
+      TD_CHECK_LAUNCH();
+      return 0;
+    }
     TD_GRID_1D(nblk, (long long)p.M * (p.N / 4), 256, "td_gemm(split-K reduce)");
     hipLaunchKernelGGL(td_gemm_splitk_reduce_kernel, dim3(nblk), dim3(256), 0, stream, ws, parts, p.M, p.N, p.bias, p.res, p.ldr, p.C, p.ldc, p.C2, p.ldc2, p.n_split);
     TD_CHECK_LAUNCH();
     return 0;
   }
-  TD_CHECK_ARG(p.split_k <= 1, "td_gemm: split_k=%d is not available for this problem (bf16 plain / bias / residual forms whose k-tile count it divides)", p.split_k);
+  TD_CHECK_ARG(p.split_k <= 1 || parts > 1, "td_gemm: split_k=%d is not available for this problem (bf16 plain / bias / residual forms whose k-tile count it divides)", p.split_k);
   if (p.q8) {
     TD_CHECK_ARG(p.i8 && p.q8_inv && p.q8_amax && p.ldq8 % 16 == 0 && ((uintptr_t)p.q8) % 16 == 0 && (p.g_M == 0 || (p.g_q8 && p.g_q8_inv && p.g_q8_amax)),
                  "td_gemm(q8 output): int8 kernels only; needs the per-row inverse scales, the amax accumulators and 16-byte aligned rows");
@@ -929,6 +1031,7 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     case 1: return launch_cfg<8, 1>(p, stream);
     case 2: return launch_cfg<1, 4>(p, stream);
     case 3: return launch_cfg<9, 3>(p, stream);
+    case 4: return launch_cfg<8, 2>(p, stream);
     default: return launch_cfg<8, 4>(p, stream);
   }
 }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void td_decode_rope_scatter_kernel(bf16_t* q, 
   float cs[8], sn[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cs[i] = cosT[(size_t)b * 128 + l16 * 8 + i]; sn[i] = sinT[(size_t)b * 128 + l16 * 8 + i]; }
-  bf16_t* dst = cache + (size_t)row_off[b];
+  bf16_t* dst = cache + (size_t)row_off[b] * KVW;      // (row index of the sequence's new cache row)
   for (int u = unit0; u < Hq + 2 * Hkv; u += 16) {
     const bool is_q = u < Hq, is_v = u >= Hq + Hkv;
     const bf16_t* src = is_q ? q + (size_t)b * QW + u * 128 + l16 * 8 : kv + (size_t)b * KVW + (u - Hq) * 128 + l16 * 8;
@@ -434,24 +434,17 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
   np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = B; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
   for (int i = 0; i < f->cfg.num_layers; ++i) {
     const QLayer& l = f->layers[i];
-    np.w = l.ln1_w;
-    TDQ_TRY(td_norm_rows_launch(np, s));
+    // (wide steps: the reduction launch of the Linear in front normalises the rows it finishes -- TdGemmParams::sk_norm_w -- so only layer 0 has a norm launch)
+    if (!wide || i == 0) {
+      np.w = l.ln1_w;
+      TDQ_TRY(td_norm_rows_launch(np, s));
+    }
     {
       TdGemmParams g;
       g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = B; g.N = QW + KVW; g.K = D;
       g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
-      if (!wide) {
-        TDQ_TRY(td_gemm_launch(g, s));
-      } else if (QW % 256 == 0) {      // (the column split needs a tile width that divides 256: as the prefill)
-        g.cfg = td_gemm_config_id(B, QW + KVW, D) == 1 ? 1 : 0;
-        g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES;
-        TDQ_TRY(td_gemm_launch(g, s));
-      } else {
-        TdGemmParams a = g; a.C2 = nullptr; a.N = QW; a.split_k = -1; a.sk_ws = f->sk_ws; a.sk_ws_bytes = SK_WS_BYTES;
-        TDQ_TRY(td_gemm_launch(a, s));
-        TdGemmParams b2 = g; b2.C2 = nullptr; b2.W = l.qkv_w + (size_t)QW * D; b2.bias = l.qkv_b + QW; b2.N = KVW; b2.C = f->kvtmp; b2.ldc = KVW; b2.split_k = -1; b2.sk_ws = f->sk_ws; b2.sk_ws_bytes = SK_WS_BYTES;
-        TDQ_TRY(td_gemm_launch(b2, s));
-      }
+      if (wide) { g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES; }      // (tile width and parts by the wide planner: n_split = Hq 128 fits its 64- / 128-column tiles)
+      TDQ_TRY(td_gemm_launch(g, s));
     }
     // rotary embedding of the new q / k rows and the cache write ride inside the attention launch (TdAttnParams::dec_kv_new);
     // td_qwen2_set_fused_rope(f, 0) / TD_QWEN2_NO_FUSED_ROPE: the separate launch (A/B and the bit-identity test)
@@ -468,11 +461,16 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
     {
       TdGemmParams g;
       g.A = f->attn; g.lda = QW; g.W = l.o_w; g.C = f->h; g.ldc = D; g.res = f->h; g.ldr = D; g.M = B; g.N = D; g.K = QW;
-      if (wide) { g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES; }
+      if (wide) {
+        g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES;
+        g.sk_norm_w = l.ln2_w; g.sk_norm_out = f->xn; g.sk_norm_ld = D; g.sk_norm_eps = f->cfg.rms_eps;
+      }
       TDQ_TRY(td_gemm_launch(g, s));
     }
-    np.w = l.ln2_w;
-    TDQ_TRY(td_norm_rows_launch(np, s));
+    if (!wide) {
+      np.w = l.ln2_w;
+      TDQ_TRY(td_norm_rows_launch(np, s));
+    }
     {
       TdGemmParams g;
       if (!wide) {
@@ -480,17 +478,24 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
         TDQ_TRY(td_gemm_launch(g, s));
       } else {      // the prefill's form: gate | up as one Linear, SiLU and product in a pass of their own (the same rounding points)
         g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = B; g.N = 2 * I; g.K = D;
+        g.split_k = -1; g.sk_ws = f->sk_ws; g.sk_ws_bytes = SK_WS_BYTES;
         TDQ_TRY(td_gemm_launch(g, s));
         TDQ_TRY(td_silu_mul_launch(f->gu, f->act, B, I, s));
       }
       TdGemmParams d;
       d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = B; d.N = D; d.K = I;
-      if (wide) { d.split_k = -1; d.sk_ws = f->sk_ws; d.sk_ws_bytes = SK_WS_BYTES; }
+      if (wide) {
+        d.split_k = -1; d.sk_ws = f->sk_ws; d.sk_ws_bytes = SK_WS_BYTES;
+        d.sk_norm_w = i + 1 < f->cfg.num_layers ? f->layers[i + 1].ln1_w : f->norm_w;      // the next layer's input norm, or model.norm
+        d.sk_norm_out = f->xn; d.sk_norm_ld = D; d.sk_norm_eps = f->cfg.rms_eps;
+      }
       TDQ_TRY(td_gemm_launch(d, s));
     }
   }
-  np.w = f->norm_w; np.y = f->xn;
-  TDQ_TRY(td_norm_rows_launch(np, s));
+  if (!wide) {
+    np.w = f->norm_w; np.y = f->xn;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+  }
   if (want_logits) {
     TdGemmParams g;
     g.A = f->xn; g.lda = D; g.W = f->lm_w; g.C = f->logits_buf; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
@@ -510,15 +515,13 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
   TD_CHECK_ARG(f && token_ids && position_ids && cache_pos, "td_qwen2_decode_batch: null argument");
   TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && B <= f->ws_rows, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots, %d workspace rows)", B, MAX_BATCH, f->n_slots, f->ws_rows);
   hipStream_t s = (hipStream_t)stream;
-  const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
-  const int QW = Hq * 128, KVW = 2 * Hkv * 128;
-  TD_CHECK_ARG((long long)B * f->slot_len * KVW < (1ll << 31), "td_qwen2_decode_batch: %d slots of %d rows exceed the 32-bit cache row offsets", B, f->slot_len);
+  const int D = f->D;
   IntPack ip;
   int max_len = 0;
   for (int b = 0; b < B; ++b) {
     TD_CHECK_ARG(cache_pos[b] >= 0 && cache_pos[b] < f->slot_len, "td_qwen2_decode_batch: sequence %d is full (%d of %d)", b, cache_pos[b], f->slot_len);
     ip.v[b] = cache_pos[b] + 1;                                         // keys visible to the new token
-    ip.v[MAX_BATCH + b] = (b * f->slot_len + cache_pos[b]) * KVW;       // its cache row (elements)
+    ip.v[MAX_BATCH + b] = b * f->slot_len + cache_pos[b];               // its cache row (index; the kernels scale it by the row width)
     max_len = cache_pos[b] + 1 > max_len ? cache_pos[b] + 1 : max_len;
   }
   hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, f->ibuf, ip, 2 * MAX_BATCH);

@@ -31,6 +31,11 @@ struct TdGemmParams {
   // kernel's rounding points.  Forms the reduction does not cover (activation, gate, int8 / fp8, conv, grouped) are launched unsplit under -1.
   int split_k = 0;
   float* sk_ws = nullptr; long long sk_ws_bytes = 0;
+  // split_k = -1 only, N % 512 == 0, N <= 4096, no second output: the reduction launch also RMS-normalises the finished row (Qwen2RMSNorm: the
+  // arithmetic, summation order and rounding points of td_norm_rows_kernel's rms form on the bf16 row it has just written) into sk_norm_out
+  // [M, sk_norm_ld] -- the norm launch that would follow the Linear (o_proj -> post_attention_layernorm, down_proj -> the next input_layernorm)
+  // disappears.  The launch then always goes through the partial-sum buffer, with one part when a split does not pay.
+  const bf16_t* sk_norm_w = nullptr; bf16_t* sk_norm_out = nullptr; int sk_norm_ld = 0; float sk_norm_eps = 1e-6f;
   int ldw = 0, k_parts = 1;      // filled by the launcher: row stride of W in elements (= the whole K), parts of a split launch (K = ONE part's extent)
   int out_f32 = 0;               // C is float* (ldc in floats): acc + bias stored unrounded, no act/gate/res
   // implicit-GEMM 3x3 convolution over an NHWC image (conv_H > 0): A = input [Hin*Win, Cin], W = [N, 9*Cin]
@@ -89,7 +94,7 @@ struct TdAttnParams {
   const int* kv_lens = nullptr;
   // decode kernel only (Sq = 1, kv_lens given): the step's rotary embedding and cache write happen INSIDE the attention launch.  Q then holds the RAW
   // q rows of the projection, dec_kv_new [batch, 2 Hkv 128] the raw new k | v rows, dec_cos / dec_sin fp32 [batch, 128] the tokens' M-RoPE table rows,
-  // dec_row_off int[batch] the element offset of each sequence's new cache row (relative to K).  Every workgroup rotates its q heads and the new key
+  // dec_row_off int[batch] the ROW index of each sequence's new cache row (x ldkv elements from K).  Every workgroup rotates its q heads and the new key
   // itself (rotate_half, every product rounded to bf16: td_decode_rope_scatter_kernel's arithmetic), uses the new key / value as the last of its
   // kv_lens[b] keys from registers, and the first workgroup of each kv head writes them to the cache -- nobody reads that row in this launch.
   const bf16_t* dec_kv_new = nullptr; const float* dec_cos = nullptr; const float* dec_sin = nullptr; const int* dec_row_off = nullptr;

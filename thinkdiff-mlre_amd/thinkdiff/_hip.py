@@ -42,7 +42,7 @@ def _declare(L):
         "td_abi_version": [],
         "td_linear_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp],
         "td_linear_split_bf16": [vp, i64, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp],
-        "td_linear_splitk_bf16": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, vp],
+        "td_linear_splitk_bf16": [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, vp, vp, i64, f32, vp],
         "td_linear_grouped2_bf16": [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, vp],
         "td_norm_rows_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, vp, i32, vp, vp, vp, vp, vp],
         "td_qk_norm_rope_bf16": [vp, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, f32, i32, vp],
@@ -179,15 +179,17 @@ def linear(x, w, bias=None, act=ACT_NONE, gate=None, res=None, out=None):
     return out
 
 
-def linear_splitk(x, w, bias=None, res=None, out=None, out1=None, n_split=0, split_k=-1, tile_cfg=-1):
-    """out = x @ w.T + bias + res with the contraction split over workgroups (td_linear_splitk_bf16); columns >= n_split go to out1 when given."""
+def linear_splitk(x, w, bias=None, res=None, out=None, out1=None, n_split=0, split_k=-1, tile_cfg=-1, norm_w=None, norm_out=None, norm_eps=1e-6):
+    """out = x @ w.T + bias + res with the contraction split over workgroups (td_linear_splitk_bf16); columns >= n_split go to out1 when given;
+    norm_w / norm_out: the reduction also writes RMSNorm(out; norm_w)."""
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and w.is_contiguous()
     if out is None:
         out = torch.empty((M, n_split if out1 is not None else N), dtype=torch.bfloat16, device=x.device)
     check(lib().td_linear_splitk_bf16(ptr(x), _rows(x), ptr(w), ptr(bias), ptr(out), _rows(out), ptr(out1), _rows(out1) if out1 is not None else 0, n_split,
-                                      M, N, K, ptr(res), _rows(res) if res is not None else 0, tile_cfg, split_k, stream_ptr()))
+                                      M, N, K, ptr(res), _rows(res) if res is not None else 0, tile_cfg, split_k,
+                                      ptr(norm_w), ptr(norm_out), _rows(norm_out) if norm_out is not None else 0, norm_eps, stream_ptr()))
     return out
 
 
