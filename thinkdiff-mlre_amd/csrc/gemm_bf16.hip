@@ -785,22 +785,23 @@ __global__ __launch_bounds__(256) void td_gemm_splitk_reduce_kernel(const float*
   else *(u32x2_t*)(C + (size_t)m * ldc + n) = o;
 }
 
-// The same reduction, one wave per row, followed by the RMSNorm of the row it has just finished (TdGemmParams::sk_norm_w).  Lane l owns columns
-// 512 c + 8 l .. + 7 of chunk c -- td_norm_rows_kernel's map -- and the sum of squares is taken in that kernel's order, so the normalised row is
-// bit-identical to the one the separate norm launch would have produced from the bf16 row written here.
+// The same reduction followed by the RMSNorm of the row it has just finished (TdGemmParams::sk_norm_w): one workgroup of NCH waves per row, wave c
+// owning the 512-column chunk c with td_norm_rows_kernel's lane map (lane l: columns 512 c + 8 l .. + 7).  That kernel adds a lane's squares chunk
+// after chunk in ONE chain before the cross-lane sum; here the chunks' bf16-rounded values meet in LDS and every wave walks the same chain, so the
+// normalised row is bit-identical to the one the separate norm launch would have produced from the bf16 row written here -- while the partial sums
+// are fetched by NCH waves at once instead of one (one wave per row: 9.8 us at N = 1536, 19 us at N = 3584 for 256 rows, more than the two launches
+// it replaced).
 template <int NCH>
-__global__ __launch_bounds__(256) void td_gemm_splitk_reduce_norm_kernel(const float* __restrict__ ws, const int parts, const int M, const bf16_t* bias, const bf16_t* res,
-                                                                         const int ldr, bf16_t* C, const int ldc, const bf16_t* nw, bf16_t* nout, const int nld, const float eps) {
+__global__ __launch_bounds__(NCH * 64) void td_gemm_splitk_reduce_norm_kernel(const float* __restrict__ ws, const int parts, const int M, const bf16_t* bias, const bf16_t* res,
+                                                                              const int ldr, bf16_t* C, const int ldc, const bf16_t* nw, bf16_t* nout, const int nld, const float eps) {
   constexpr int N = NCH * 512;
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
+  __shared__ float xs[NCH][8][64];      // [chunk][element][lane]: conflict-free for the lane-contiguous accesses below
+  const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+  const int m = blockIdx.x;
   const size_t slab = (size_t)M * N;
-  float x[NCH][8];
-  float sq = 0.f;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int n = c * 512 + lane * 8;
+  const int n = c * 512 + lane * 8;
+  float x[8];
+  {
     const float* src = ws + (size_t)m * N + n;
     f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
     for (int k = 1; k < parts; ++k) { a += *(const f32x4_t*)(src + (size_t)k * slab); b += *(const f32x4_t*)(src + (size_t)k * slab + 4); }
@@ -818,26 +819,26 @@ __global__ __launch_bounds__(256) void td_gemm_splitk_reduce_norm_kernel(const f
     const u32x4_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
     *(u32x4_t*)(C + (size_t)m * ldc + n) = o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { x[c][2 * i] = bf_lo(o[i]); x[c][2 * i + 1] = bf_hi(o[i]); }
+    for (int i = 0; i < 4; ++i) { x[2 * i] = bf_lo(o[i]); x[2 * i + 1] = bf_hi(o[i]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[c][i][lane] = x[i];
   }
-  // td_norm_rows_kernel, rms form: the squares are added chunk by chunk, element by element, then across the wave
+  __syncthreads();
+  // td_norm_rows_kernel, rms form: a lane's squares are added chunk by chunk, element by element, then across the wave
+  float sq = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sq += x[c][i] * x[c][i];
+    for (int i = 0; i < 8; ++i) { const float t = xs[cc][i][lane]; sq += t * t; }
   const float rstd = rsqrtf(wave_sum(sq) * (1.0f / N) + eps);
+  const u32x4_t wr = *(const u32x4_t*)(nw + n);
+  float y[8];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int n = c * 512 + lane * 8;
-    const u32x4_t wr = *(const u32x4_t*)(nw + n);
-    float y[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      y[2 * i] = rbf(rbf(x[c][2 * i] * rstd) * bf_lo(wr[i]));
-      y[2 * i + 1] = rbf(rbf(x[c][2 * i + 1] * rstd) * bf_hi(wr[i]));
-    }
-    *(u32x4_t*)(nout + (size_t)m * nld + n) = u32x4_t{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
+  for (int i = 0; i < 4; ++i) {
+    y[2 * i] = rbf(rbf(x[2 * i] * rstd) * bf_lo(wr[i]));
+    y[2 * i + 1] = rbf(rbf(x[2 * i + 1] * rstd) * bf_hi(wr[i]));
   }
+  *(u32x4_t*)(nout + (size_t)m * nld + n) = u32x4_t{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]), pack_bf2(y[4], y[5]), pack_bf2(y[6], y[7])};
 }
 
 namespace {
@@ -953,10 +954,10 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     TD_CHECK_ARG(p.M <= 64 && p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.conv_H == 0, "td_gemm: the gated form exists for the skinny-M kernels only (M <= 64)");
     return td_gemv_launch(p, stream);
   }
-  if (p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.cfg < 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);
+  if (p.g_M == 0 && !p.fp8 && !p.i8 && !p.out_f32 && p.cfg < 0 && p.split_k == 0 && p.N % 4 == 0 && (p.M <= 16 || (p.M <= 64 && td_gemv_mfma_ok(p)))) return td_gemv_launch(p, stream);      // (a caller that sets split_k wants the tile kernels)
   int cfg = p.cfg >= 0 ? p.cfg : td_gemm_config_id(p.M + p.g_M, p.N, p.K * esz / 2);
   int parts = 1;
-  if (p.split_k == -1 && p.cfg < 0 && p.M > 64 && p.M <= 256 && !p.fp8 && !p.i8 && p.g_M == 0 && !p.out_f32 && !p.q8) {
+  if (p.split_k == -1 && p.cfg < 0 && p.M > 16 && p.M <= 256 && !p.fp8 && !p.i8 && p.g_M == 0 && !p.out_f32 && !p.q8) {
     const WidePlan w = plan_wide(p);
     cfg = w.cfg; parts = w.parts;
   } else {
@@ -965,9 +966,9 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
   const bool fuse_norm = p.sk_norm_w != nullptr;
   if (fuse_norm) {
     TD_CHECK_ARG(p.split_k == -1 && p.sk_norm_out && !p.C2 && p.N % 512 == 0 && p.N <= 4096 && p.sk_norm_ld % 8 == 0 && plan_split_k(p, cfg) >= 1 && !p.fp8 && !p.i8 &&
-                     p.conv_H == 0 && p.g_M == 0 && !p.out_f32 && p.act == TD_ACT_NONE && !p.gate && !p.q8 && p.M > 64 &&
+                     p.conv_H == 0 && p.g_M == 0 && !p.out_f32 && p.act == TD_ACT_NONE && !p.gate && !p.q8 && p.M > 16 &&
                      (long long)p.M * p.N * 4 <= (p.sk_ws ? p.sk_ws_bytes : SPLITK_POOL_BYTES),
-                 "td_gemm(sk_norm): plain / bias / residual bf16 launches under split_k = -1, N %% 512 == 0, N <= 4096, M > 64");
+                 "td_gemm(sk_norm): plain / bias / residual bf16 launches under split_k = -1, N %% 512 == 0, N <= 4096, M > 16");
   }
   if (parts > 1 || fuse_norm) {
     float* ws = p.sk_ws;
@@ -987,9 +988,9 @@ int td_gemm_launch(const TdGemmParams& p, hipStream_t stream) {
     }
     if (rc) return rc;
     if (fuse_norm) {
-      const dim3 g((p.M + 3) / 4), b(256);
+      const dim3 g(p.M);
       switch (p.N / 512) {
-#define TD_CASE(n) case n: hipLaunchKernelGGL(td_gemm_splitk_reduce_norm_kernel<n>, g, b, 0, stream, ws, parts, p.M, p.bias, p.res, p.ldr, p.C, p.ldc, p.sk_norm_w, p.sk_norm_out, p.sk_norm_ld, p.sk_norm_eps); break;
+#define TD_CASE(n) case n: hipLaunchKernelGGL(td_gemm_splitk_reduce_norm_kernel<n>, g, dim3(n * 64), 0, stream, ws, parts, p.M, p.bias, p.res, p.ldr, p.C, p.ldc, p.sk_norm_w, p.sk_norm_out, p.sk_norm_ld, p.sk_norm_eps); break;
         TD_CASE(1) TD_CASE(2) TD_CASE(3) TD_CASE(4) TD_CASE(5) TD_CASE(6) TD_CASE(7) TD_CASE(8)
 #undef TD_CASE
       }

@@ -426,7 +426,12 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
   const int* kv_lens = f->ibuf;
   const int* row_off = f->ibuf + MAX_BATCH;
-  const bool wide = B > STREAM_BATCH;
+  // Cross-over between the weight-stream kernels and the tile kernels, measured on both decoder shapes (profiles/r4z_decode_crossover.log): the 2B
+  // shape (hidden 1536) stays ahead on the stream through 64 sequences (2.68 vs 2.79 ms per step), the 7B shape (hidden 3584) is level at 24 and
+  // 18 % ahead on the tiles at 64 (5.44 vs 6.63 ms).  TD_QWEN2_STREAM_BATCH (>= 16): A/B.
+  static const int env_stream_batch = getenv("TD_QWEN2_STREAM_BATCH") ? atoi(getenv("TD_QWEN2_STREAM_BATCH")) : 0;
+  const int stream_batch = env_stream_batch > 0 ? (env_stream_batch < 16 ? 16 : env_stream_batch) : (D >= 3072 ? 32 : STREAM_BATCH);
+  const bool wide = B > stream_batch;
 
   TDQ_TRY(td_embed_gather_launch(f->tok_buf, f->embed_w, f->h, B, D, f->cfg.vocab, s));
   TDQ_TRY(td_mrope_table_launch(f->pos_buf, B, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
