@@ -119,17 +119,46 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
   // The loop is a chain of dependent HBM / L2 round trips (one key row per slot and trip: ~0.6 us each, 19 trips for 300 keys = the 12 us the
   // kernel took per layer at one sequence): four keys per slot are fetched before the first is used, so a trip's latency covers four keys.
   // The keys of a slot are still visited in increasing order, so the arithmetic -- and the result -- is unchanged.
-  constexpr int UN = 4;
+  // ... and the NEXT four are requested before the current four are used (register double buffer): with several query heads per workgroup the
+  // arithmetic of a trip (~35 instructions per key and head) is as long as its fetch, and the two alternated instead of overlapping.
+  constexpr int UN = G >= 6 ? 2 : 4;      // (6 / 7 heads per workgroup: two keys per buffer keep the kernel inside 256 registers, i.e. two waves per SIMD)
   int key = slot;
-  for (; key + 16 * (UN - 1) < len_cache; key += 16 * UN) {
+  if constexpr (G == 1) {      // one head per workgroup (small batches: the grid is heads x sequences): a trip is all fetch, nothing to overlap it with
+    for (; key + 16 * (UN - 1) < len_cache; key += 16 * UN) {
+      u32x4_t kk[UN], vv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        kk[u] = *(const u32x4_t*)(Kb + (size_t)(key + 16 * u) * p.ldkv);
+        vv[u] = *(const u32x4_t*)(Vb + (size_t)(key + 16 * u) * p.ldkv);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) one_key(kk[u], vv[u]);
+    }
+  } else if (key + 16 * (UN - 1) < len_cache) {
     u32x4_t kk[UN], vv[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       kk[u] = *(const u32x4_t*)(Kb + (size_t)(key + 16 * u) * p.ldkv);
       vv[u] = *(const u32x4_t*)(Vb + (size_t)(key + 16 * u) * p.ldkv);
     }
+    for (;;) {
+      const int nkey = key + 16 * UN;
+      const bool more = nkey + 16 * (UN - 1) < len_cache;
+      u32x4_t kn[UN], vn[UN];
+      if (more) {
 #pragma unroll
-    for (int u = 0; u < UN; ++u) one_key(kk[u], vv[u]);
+        for (int u = 0; u < UN; ++u) {
+          kn[u] = *(const u32x4_t*)(Kb + (size_t)(nkey + 16 * u) * p.ldkv);
+          vn[u] = *(const u32x4_t*)(Vb + (size_t)(nkey + 16 * u) * p.ldkv);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) one_key(kk[u], vv[u]);
+      key = nkey;
+      if (!more) break;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { kk[u] = kn[u]; vv[u] = vn[u]; }
+    }
   }
   for (; key < len_cache; key += 16) {
     const u32x4_t kk = *(const u32x4_t*)(Kb + (size_t)key * p.ldkv);
