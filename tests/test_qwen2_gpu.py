@@ -354,3 +354,34 @@ def test_full_width_qwen2_7b_layers(hip):
     assert e_pre < 2e-2 and e_dec < 2e-2 and e_bat < 2e-2
     assert e32 < 1.5 * eref + 2e-3
     assert all(o["hidden_states"].shape == (k, 3584) for o in many)
+
+
+@pytest.mark.parametrize("B", [40, 130])
+def test_full_width_qwen2_7b_layers_wide_decode(hip, B):
+    """The 7B layer shapes in the decode regime the tile kernels own (from 33 sequences on this width: split-K Linears on the 64- / 128- / 256-column
+    tiles, the reduction launches that also normalise 3584-wide rows, 7 query heads per decode-attention workgroup): B sequences per step, the first
+    one the oracle's 300-token image-like request, teacher-forced -- its decode states against the oracle and against the one-sequence path."""
+    from thinkdiff.models.qwen2_vl import SamplingParams
+    cfg = Q.tiny_config(hidden=3584, num_layers=2, num_heads=28, num_kv_heads=4, intermediate=18944, vocab=4096)
+    sd = Q.init_weights(cfg, seed=31)
+    g = torch.Generator().manual_seed(6)
+    n, k = 300, 6
+    ids = torch.randint(0, cfg.vocab, (n + k,), generator=g)
+    pos = torch.stack([torch.arange(n + k), torch.arange(n + k) // 3 + 2, (torch.arange(n + k) * 2) % 11]).to(torch.int32)
+    pos[:, n:] = pos[:, :n].max() + 1 + torch.arange(k, dtype=torch.int32)
+    ref, _ = Q.text_model_hidden(sd, cfg, pos, token_ids=ids)
+    sp = SamplingParams(max_tokens=k, min_tokens=k, ignore_eos=True)
+    e = _engine(cfg, sd, max_len=B * 320)
+    one = e.generate(ids[:n].tolist(), sp, position_ids=pos[:, :n], forced_output_ids=ids[n:].tolist())
+    one = {k_: (v.clone() if torch.is_tensor(v) else v) for k_, v in one.items()}
+    e.set_slots(B)
+    assert e.slot_len == 320
+    reqs = [{"prompt_token_ids": ids[:n].tolist(), "position_ids": pos[:, :n]}] + \
+           [{"prompt_token_ids": torch.randint(0, cfg.vocab, (5 + (13 * b) % 90,), generator=g).tolist()} for b in range(B - 1)]
+    forced = [ids[n:].tolist()] + [torch.randint(0, cfg.vocab, (k,), generator=g).tolist() for _ in range(B - 1)]
+    many = e.generate_batch(reqs, sp, forced_output_ids=forced)
+    torch.cuda.synchronize()
+    e_bat, e_one = _rel(many[0]["hidden_states"], ref[n:]), _rel(many[0]["hidden_states"], one["hidden_states"])
+    print(f"7B-width layers, {B} sequences per step: decode vs oracle {e_bat:.4f}, vs the one-sequence path {e_one:.4f}")
+    assert e_bat < 2e-2 and e_one < 2e-2
+    assert all(o["hidden_states"].shape == (k, 3584) and torch.isfinite(o["hidden_states"].float()).all() for o in many)
