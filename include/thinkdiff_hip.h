@@ -407,6 +407,13 @@ int td_qwen2_prefill_batch(td_qwen2* f, int B, int L, const int* token_ids, cons
 /* ... into slots slot0..slot0+B-1: a request batch with B x L above ws_rows is prefilled in several calls */
 int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* token_ids, const void* inputs_embeds, const int* position_ids,
                               const int* lens, void* hidden_out, void* logits_last, void* stream);
+/* Packed prefill: the B prompts lie back to back -- rows [sum(lens[:b]), sum(lens[:b+1])) belong to sequence b, no padding rows -- and go to cache
+ * slots slot0 .. slot0 + B - 1: what vLLM's scheduler does with the reference's request batches (max_num_batched_tokens rows per pass,
+ * configs/qwen2_vl_embed_ccsbu.yaml:19; thinkdiff/models/mllama_vllm_generate_1.py:585).  total = sum(lens) <= the handle's workspace rows.
+ * token_ids int32[total] or inputs_embeds bf16[total, hidden]; position_ids int32[3, total]; lens HOST int[B]; hidden_out bf16[total, hidden];
+ * logits_last bf16[B, vocab] of each prompt's last token (either output may be NULL). */
+int td_qwen2_prefill_packed(td_qwen2* f, int slot0, int B, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                            const int* lens, void* hidden_out, void* logits_last, void* stream);
 int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache rows of an existing handle */
 /* Decode step: the rotary embedding of the new q / k rows and the write of the new k | v rows into the cache happen inside the decode-attention
  * launch (default, one launch per layer fewer) or in a launch of their own (on = 0: A/B and the bit-identity test).  Same arithmetic either way

@@ -385,3 +385,51 @@ def test_full_width_qwen2_7b_layers_wide_decode(hip, B):
     print(f"7B-width layers, {B} sequences per step: decode vs oracle {e_bat:.4f}, vs the one-sequence path {e_one:.4f}")
     assert e_bat < 2e-2 and e_one < 2e-2
     assert all(o["hidden_states"].shape == (k, 3584) and torch.isfinite(o["hidden_states"].float()).all() for o in many)
+
+
+def test_packed_prefill_equals_padded_and_single(hip):
+    """td_qwen2_prefill_packed (prompts back to back, causal attention per packed segment, k|v rows scattered to their slots) against the right-padded
+    batched prefill and against one request at a time: prompt states, first sampled logits (through greedy continuation) and the cache (through
+    teacher-forced decode steps).  Lengths from 1 token to several query tiles, one request with distinct M-RoPE streams, one with inputs_embeds,
+    and a workspace small enough to force several passes."""
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=17)
+    tc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                           intermediate_size=cfg.intermediate, vocab_size=cfg.vocab, tie_word_embeddings=cfg.tie_embeddings)
+    g = torch.Generator().manual_seed(3)
+    lens = [1, 300, 7, 64, 257, 33, 512, 5, 129, 90, 2, 256]
+    reqs = [{"prompt_token_ids": torch.randint(0, cfg.vocab, (n,), generator=g).tolist()} for n in lens]
+    reqs[4]["position_ids"] = torch.stack([torch.arange(257), torch.arange(257) // 3 + 2, (torch.arange(257) * 2) % 11]).to(torch.int32)
+    forced = [torch.randint(0, cfg.vocab, (4,), generator=g).tolist() for _ in lens]
+    sp = SamplingParams(max_tokens=4, min_tokens=4, ignore_eos=True)
+    outs = {}
+    for mode in ("single", "padded", "packed"):
+        e = Qwen2VLTextEngine(tc, max_model_len=640, n_slots=len(lens), prefill_rows=1100)        # 1656 prompt rows: two packed passes, several padded ones
+        e.load_state_dict(sd)
+        if mode == "single":
+            e.set_slots(1)
+            res = [e.generate(r["prompt_token_ids"], sp, position_ids=r.get("position_ids"), forced_output_ids=f) for r, f in zip(reqs, forced)]
+            res = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in res]
+        else:
+            e.packed_prefill = mode == "packed"
+            rr = [dict(r) for r in reqs]
+            if mode == "packed":
+                rr[3]["inputs_embeds"] = e.embed_tokens(rr[3]["prompt_token_ids"])        # a request that brings its own embeddings (spliced vision rows)
+            res = e.generate_batch(rr, sp, forced_output_ids=forced)
+        torch.cuda.synchronize()
+        outs[mode] = res
+    for a, b, c, n in zip(outs["single"], outs["padded"], outs["packed"], lens):
+        assert c["prompt_hidden_states"].shape == (n, cfg.hidden) and c["hidden_states"].shape == (4, cfg.hidden)
+        assert torch.isfinite(c["prompt_hidden_states"].float()).all()
+        assert _rel(c["prompt_hidden_states"], a["prompt_hidden_states"]) < 5e-3 and _rel(c["hidden_states"], a["hidden_states"]) < 5e-3
+        assert _rel(c["prompt_hidden_states"], b["prompt_hidden_states"]) < 5e-3 and _rel(c["hidden_states"], b["hidden_states"]) < 5e-3
+    # sampled continuation from the packed prefill's logits: greedy = the one-request path's tokens
+    sp0 = SamplingParams(temperature=0.0, max_tokens=5, min_tokens=5, ignore_eos=True)
+    e = Qwen2VLTextEngine(tc, max_model_len=640, n_slots=4, prefill_rows=1100)
+    e.load_state_dict(sd)
+    gb = e.generate_batch(reqs[1:5], sp0)
+    e.set_slots(1)
+    for r, o in zip(reqs[1:5], gb):
+        ref = e.generate(r["prompt_token_ids"], sp0, position_ids=r.get("position_ids"))
+        assert o["token_ids"] == ref["token_ids"]

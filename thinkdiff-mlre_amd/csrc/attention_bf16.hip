@@ -549,7 +549,15 @@ int td_attn_launch(const TdAttnParams& p, hipStream_t stream) {
   if (p.q8) TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && !p.seg_starts && p.batch == 1 && p.q8_inv && p.q8_amax && p.ldq8 % 8 == 0 && ((uintptr_t)p.q8) % 8 == 0,
                          "td_attention: the int8 output form is for the joint attention of one batch entry, with 8-byte aligned rows");
   if (p.seg_starts) {   // packed segments: plain grid over (query tiles of the longest segment, heads, segments)
-    TD_CHECK_ARG(!p.causal && !p.bias && !p.kv_lens && p.Sq == p.Skv, "td_attention(varlen): full attention inside each segment only (no mask, bias or cache lengths)");
+    TD_CHECK_ARG(!p.bias && !p.kv_lens && p.Sq == p.Skv && (!p.causal || p.causal_offset == 0),
+                 "td_attention(varlen): full or causal (offset 0) attention inside each segment only (no bias or cache lengths)");
+    if (p.causal) {      // packed causal prefill of the Qwen2-VL engine (prompts of different lengths back to back, no padding rows)
+      static std::atomic<unsigned long long> a12{0};
+      if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<true, NW, false, true>, lds, a12, dev)) return e;
+      hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<true, NW, false, true>), grid, dim3(NW * 64), lds, stream, q);
+      TD_CHECK_LAUNCH();
+      return 0;
+    }
     static std::atomic<unsigned long long> a6{0};
     if (int e = set_lds_attr_once(td_attn_fwd_d128_lean_kernel<false, NW, false, true>, lds, a6, dev)) return e;
     hipLaunchKernelGGL((td_attn_fwd_d128_lean_kernel<false, NW, false, true>), grid, dim3(NW * 64), lds, stream, q);

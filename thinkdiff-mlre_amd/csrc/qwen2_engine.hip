@@ -66,6 +66,8 @@ struct td_qwen2 {
   bool fused_rope = true;                       // decode: rotary embedding + cache write inside the attention launch (td_qwen2_set_fused_rope)
   int *tok_buf = nullptr, *pos_buf = nullptr;   // [MAX_BATCH], [3, MAX_BATCH]: the step's token and position ids
   bf16_t* logits_buf = nullptr;                 // [MAX_BATCH, vocab]
+  int* row_map = nullptr;                       // [ws_rows] packed prefill: cache row of every packed prompt row
+  std::vector<int> row_map_host;                // ... its host image (kept alive across the asynchronous upload)
   float* sk_ws = nullptr;                       // partial sums of the decode step's split-K Linears (65-256 sequences): the engine's own buffer, so a captured step allocates nothing
 };
 
@@ -100,6 +102,19 @@ __global__ void td_kv_rows_to_slots_kernel(const bf16_t* src, bf16_t* dst_base, 
   const int b = row / L, t = row - b * L;
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (c < W) *(u32x4_t*)(dst_base + ((size_t)b * slot_len + t) * W + c) = *(const u32x4_t*)(src + (size_t)row * W + c);
+}
+
+// packed prefill: row r of src (prompts back to back) -> cache row dst_row[r] (its sequence's slot and position)
+__global__ void td_kv_rows_to_rows_kernel(const bf16_t* src, bf16_t* dst_base, const int* dst_row, int W) {
+  const int row = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c < W) *(u32x4_t*)(dst_base + (size_t)dst_row[row] * W + c) = *(const u32x4_t*)(src + (size_t)row * W + c);
+}
+// dst[b, :] = src[seg_starts[b + 1] - 1, :]: the last row of every packed segment (lm_head input)
+__global__ void td_gather_last_rows_kernel(const bf16_t* src, bf16_t* dst, const int* seg_starts, int D) {
+  const int b = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c < D) *(u32x4_t*)(dst + (size_t)b * D + c) = *(const u32x4_t*)(src + (size_t)(seg_starts[b + 1] - 1) * D + c);
 }
 
 // Decode step, one launch for: M-RoPE on the new q rows (in place), M-RoPE on the new k rows, k|v rows -> their sequences' cache
@@ -217,7 +232,7 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
       {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
       {(void**)&f->kvtmp, n * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4}, {(void**)&f->lastrows, (int64_t)MAX_BATCH * D * 2},
       {(void**)&f->tok_buf, MAX_BATCH * 4}, {(void**)&f->pos_buf, 3 * MAX_BATCH * 4}, {(void**)&f->logits_buf, (int64_t)MAX_BATCH * cfg->vocab * 2},
-      {(void**)&f->sk_ws, SK_WS_BYTES},
+      {(void**)&f->sk_ws, SK_WS_BYTES}, {(void**)&f->row_map, n * 4},
   };
   int64_t total = 0;
   for (auto& r : reqs) total += (r.bytes + 255) & ~int64_t(255);
@@ -649,6 +664,107 @@ int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* t
   if (logits_last) {
     for (int b = 0; b < B; ++b)
       TD_CHECK_HIP(hipMemcpyAsync(f->lastrows + (size_t)b * D, f->xn + ((size_t)b * L + lens[b] - 1) * D, (size_t)D * 2, hipMemcpyDeviceToDevice, s));
+    TdGemmParams g;
+    g.A = f->lastrows; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits_last; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
+    TDQ_TRY(td_gemm_launch(g, s));
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+
+// Packed prefill: the B prompts lie back to back (row offsets = the running sum of lens; no padding rows), sequence b goes to cache slot slot0 + b.
+// What vLLM's scheduler does with the reference's request batches (max_num_batched_tokens rows per pass); against the padded form it saves the
+// rows between each prompt and the longest.  total = sum(lens) rows: inputs_embeds bf16[total, hidden] or token_ids int32[total]; position_ids
+// int32[3, total]; hidden_out bf16[total, hidden]; logits_last bf16[B, vocab] of each prompt's last token (either output may be NULL).
+int td_qwen2_prefill_packed(td_qwen2* f, int slot0, int B, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                            const int* lens, void* hidden_out, void* logits_last, void* stream) {
+  TD_CHECK_ARG(f && position_ids && lens && (token_ids || inputs_embeds), "td_qwen2_prefill_packed: null argument");
+  TD_CHECK_ARG(slot0 >= 0 && B >= 1 && B <= MAX_BATCH && slot0 + B <= f->n_slots, "td_qwen2_prefill_packed: slots [%d, %d) exceed the handle's %d", slot0, slot0 + B, f->n_slots);
+  long long total = 0;
+  int L = 0;
+  for (int b = 0; b < B; ++b) {
+    TD_CHECK_ARG(lens[b] >= 1 && lens[b] <= f->slot_len, "td_qwen2_prefill_packed: sequence %d has %d tokens (slot capacity %d)", b, lens[b], f->slot_len);
+    total += lens[b];
+    L = lens[b] > L ? lens[b] : L;
+  }
+  TD_CHECK_ARG(total <= f->ws_rows, "td_qwen2_prefill_packed: %lld packed rows exceed the %d workspace rows", total, f->ws_rows);
+  hipStream_t s = (hipStream_t)stream;
+  const int D = f->D, I = f->I, Hq = f->Hq, Hkv = f->Hkv;
+  const int QW = Hq * 128, KVW = 2 * Hkv * 128, n = (int)total;
+  // segment starts (device, for the attention and the last-row gather) and the cache row of every packed row
+  IntPack ip;
+  int* seg_starts = f->ibuf + 2 * MAX_BATCH;      // [B + 1] behind the decode step's lengths and rows
+  static_assert(MAX_BATCH + 1 <= 2 * MAX_BATCH, "seg_starts fit one IntPack");
+  f->row_map_host.resize((size_t)n);
+  int r = 0;
+  for (int b = 0; b < B; ++b) {
+    ip.v[b] = r;
+    for (int t = 0; t < lens[b]; ++t) f->row_map_host[(size_t)r + t] = (slot0 + b) * f->slot_len + t;
+    r += lens[b];
+  }
+  ip.v[B] = r;
+  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, seg_starts, ip, B + 1);
+  TD_CHECK_LAUNCH();
+  TD_CHECK_HIP(hipMemcpyAsync(f->row_map, f->row_map_host.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  if (inputs_embeds) TD_CHECK_HIP(hipMemcpyAsync(f->h, inputs_embeds, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));
+  else TDQ_TRY(td_embed_gather_launch(token_ids, f->embed_w, f->h, n, D, f->cfg.vocab, s));
+  TDQ_TRY(td_mrope_table_launch(position_ids, n, f->cfg.mrope_section, f->cfg.rope_theta, 1, f->cosT, f->sinT, s));
+  TdNormParams np;
+  np.x = f->h; np.ldx = D; np.y = f->xn; np.ldy = D; np.rows = n; np.D = D; np.rms = 1; np.eps = f->cfg.rms_eps;
+  TdQkRopeParams rq;
+  rq.qkv = f->q; rq.ld = QW; rq.rows = n; rq.Hq = Hq; rq.Hk = 0; rq.q_col = 0; rq.k_col = 0;
+  rq.cos = f->cosT; rq.sin = f->sinT; rq.rotate_half = 2;
+  TdQkRopeParams rk = rq;
+  rk.qkv = f->kvtmp; rk.ld = KVW; rk.Hq = Hkv;
+  for (int i = 0; i < f->cfg.num_layers; ++i) {
+    const QLayer& l = f->layers[i];
+    np.w = l.ln1_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.qkv_w; g.bias = l.qkv_b; g.M = n; g.N = QW + KVW; g.K = D;
+      g.C = f->q; g.ldc = QW; g.C2 = f->kvtmp; g.ldc2 = KVW; g.n_split = QW;
+      if (QW % 256 == 0) {
+        g.cfg = n <= 32 ? -1 : (td_gemm_config_id(n, QW + KVW, D) == 1 ? 1 : 0);
+        TDQ_TRY(td_gemm_launch(g, s));
+      } else {
+        TdGemmParams a = g; a.C2 = nullptr; a.N = QW;
+        TDQ_TRY(td_gemm_launch(a, s));
+        TdGemmParams b2 = g; b2.C2 = nullptr; b2.W = l.qkv_w + (size_t)QW * D; b2.bias = l.qkv_b + QW; b2.N = KVW; b2.C = f->kvtmp; b2.ldc = KVW;
+        TDQ_TRY(td_gemm_launch(b2, s));
+      }
+    }
+    TDQ_TRY(td_qk_norm_rope_launch(rq, s));
+    TDQ_TRY(td_qk_norm_rope_launch(rk, s));
+    hipLaunchKernelGGL(td_kv_rows_to_rows_kernel, dim3((KVW / 8 + 255) / 256, n), dim3(256), 0, s, f->kvtmp, l.kv, f->row_map, KVW);
+    TdAttnParams ap;      // causal attention inside each packed prompt, straight from the projection rows (a prefill starts at position 0)
+    ap.Q = f->q; ap.ldq = QW; ap.K = f->kvtmp; ap.V = f->kvtmp + Hkv * 128; ap.ldkv = KVW; ap.O = f->attn; ap.ldo = QW;
+    ap.batch = B; ap.Sq = L; ap.Skv = L; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f; ap.causal = 1; ap.causal_offset = 0;
+    ap.seg_starts = seg_starts;
+    TDQ_TRY(td_attn_launch(ap, s));
+    {
+      TdGemmParams g;
+      g.A = f->attn; g.lda = QW; g.W = l.o_w; g.C = f->h; g.ldc = D; g.res = f->h; g.ldr = D; g.M = n; g.N = D; g.K = QW;
+      TDQ_TRY(td_gemm_launch(g, s));
+    }
+    np.w = l.ln2_w;
+    TDQ_TRY(td_norm_rows_launch(np, s));
+    {
+      TdGemmParams g;
+      g.A = f->xn; g.lda = D; g.W = l.gu_w; g.C = f->gu; g.ldc = 2 * I; g.M = n; g.N = 2 * I; g.K = D;
+      TDQ_TRY(td_gemm_launch(g, s));
+      TDQ_TRY(td_silu_mul_launch(f->gu, f->act, n, I, s));
+      TdGemmParams d;
+      d.A = f->act; d.lda = I; d.W = l.down_w; d.C = f->h; d.ldc = D; d.res = f->h; d.ldr = D; d.M = n; d.N = D; d.K = I;
+      TDQ_TRY(td_gemm_launch(d, s));
+    }
+  }
+  np.w = f->norm_w; np.y = f->xn;
+  TDQ_TRY(td_norm_rows_launch(np, s));
+  if (hidden_out) TD_CHECK_HIP(hipMemcpyAsync(hidden_out, f->xn, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));
+  if (logits_last) {
+    hipLaunchKernelGGL(td_gather_last_rows_kernel, dim3((D / 8 + 255) / 256, B), dim3(256), 0, s, f->xn, f->lastrows, seg_starts, D);
     TdGemmParams g;
     g.A = f->lastrows; g.lda = D; g.W = f->lm_w; g.C = (bf16_t*)logits_last; g.ldc = f->cfg.vocab; g.M = B; g.N = f->cfg.vocab; g.K = D;
     TDQ_TRY(td_gemm_launch(g, s));

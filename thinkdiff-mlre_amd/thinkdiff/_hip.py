@@ -116,6 +116,7 @@ def _declare(L):
         "td_qwen2_create_ex": [vp, i32, i32, i32, vp],
         "td_qwen2_prefill_batch": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
         "td_qwen2_prefill_batch_at": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+        "td_qwen2_prefill_packed": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
         "td_qwen2_slot_capacity": [vp],
         "td_qwen2_move_slot": [vp, i32, i32, i32, vp],
         "td_qwen2_decode_batch": [vp, i32, vp, vp, vp, vp, vp, vp],

@@ -34,7 +34,7 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         # vLLM decodes `max_num_seqs` requests together (256 in configs/qwen2_vl_embed_ccsbu.yaml); the engine takes up to 256 per decode step
         self.decode_batch = max(1, min(Qwen2VLTextEngine.MAX_BATCH, int(vc.get("max_num_seqs", Qwen2VLTextEngine.MAX_BATCH))))
         self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch,
-                                        prefill_rows=min(int(vc.get("max_num_batched_tokens", 16384)), 16384) if self.decode_batch > 1 else None)
+                                        prefill_rows=min(int(vc.get("max_num_batched_tokens", 16384)), 65536) if self.decode_batch > 1 else None)      # (60 000 in the reference config: rows of one packed prefill pass)
         self.mllama_sampling_params = SamplingParams(
             temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 256),
             min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False))

@@ -38,7 +38,7 @@ class MllamaVllmT5EmbedDecoderForConditionalGeneration_5(QwenChatFrontend, BaseM
         self.config = SimpleNamespace(vllm_config=vc, mm_projector_type=mm_projector_type,
                                       mm_hidden_size=(text_config or Qwen2VLTextConfig()).hidden_size, hidden_size=hidden_size)
         self._device = torch.device(device)
-        # vLLM decodes up to `max_num_seqs` requests together; here up to 64 sequences share each pass over the weights
+        # vLLM decodes up to `max_num_seqs` requests together; the engine advances up to 256 per decode step
         self.decode_batch = max(1, min(Qwen2VLTextEngine.MAX_BATCH, int(vc.get("max_num_seqs", 1))))
         self.mllama = Qwen2VLTextEngine(text_config, max_model_len=vc.get("max_model_len", 8192), device=device, n_slots=self.decode_batch,
                                         prefill_rows=min(int(vc.get("max_num_batched_tokens", 16384)), 16384) if self.decode_batch > 1 else None)

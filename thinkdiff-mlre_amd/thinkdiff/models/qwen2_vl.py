@@ -263,6 +263,7 @@ class Qwen2VLTextEngine:
         dev = generator.device if generator is not None else "cpu"
         return int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=dev))
 
+    packed_prefill = True   # generate_batch: prompts back to back (td_qwen2_prefill_packed); False = right-padded to the longest (td_qwen2_prefill_batch_at: A/B, tests)
     MAX_BATCH = 256     # td_qwen2_decode_batch: sequences sharing one decode step (vLLM's max_num_seqs of the precompute job)
 
     @torch.no_grad()
@@ -280,7 +281,37 @@ class Qwen2VLTextEngine:
         poss = [self.text_position_ids(n) if r.get("position_ids") is None else r["position_ids"] for r, n in zip(requests, cache_len)]
         next_pos = [int(p.max()) + 1 for p in poss]
         L = (max(cache_len) + 7) // 8 * 8
-        if B > 1 and L <= self.slot_len and 2 * L <= self.prefill_rows:
+        if B > 1 and self.packed_prefill and max(cache_len) <= min(self.slot_len, self.prefill_rows):
+            # packed prefill (td_qwen2_prefill_packed): the prompts of a pass lie back to back, no padding rows -- vLLM's batching of the
+            # reference's requests; a pass takes as many prompts as the activation workspace (max_num_batched_tokens) holds
+            D = self.config.hidden_size
+            logits = torch.empty(B, self.config.vocab_size, dtype=torch.bfloat16, device=self.device)
+            b0 = 0
+            while b0 < B:
+                nb, rows = 0, 0
+                while b0 + nb < B and nb < self.MAX_BATCH and rows + cache_len[b0 + nb] <= self.prefill_rows:
+                    rows += cache_len[b0 + nb]
+                    nb += 1
+                emb = torch.empty(rows, D, dtype=torch.bfloat16, device=self.device)
+                pos = torch.empty(3, rows, dtype=torch.int32)
+                r = 0
+                for j in range(nb):
+                    q, n, pp = requests[b0 + j], cache_len[b0 + j], poss[b0 + j]
+                    e = q.get("inputs_embeds")
+                    emb[r:r + n] = self.embed_tokens(q["prompt_token_ids"]) if e is None else e.to(self.device, torch.bfloat16)
+                    pos[:, r:r + n] = pp.to(torch.int32)
+                    r += n
+                pos = pos.to(self.device).contiguous()
+                hid = torch.empty(rows, D, dtype=torch.bfloat16, device=self.device)
+                lens = (ctypes.c_int * nb)(*cache_len[b0:b0 + nb])
+                _hip.check(self._L.td_qwen2_prefill_packed(self._h, b0, nb, None, _hip.ptr(emb), _hip.ptr(pos), ctypes.cast(lens, ctypes.c_void_p),
+                                                           _hip.ptr(hid), _hip.ptr(logits[b0:b0 + nb]), _hip.stream_ptr()))
+                r = 0
+                for j in range(nb):
+                    res[b0 + j]["prompt_hidden_states"] = hid[r:r + cache_len[b0 + j]]
+                    r += cache_len[b0 + j]
+                b0 += nb
+        elif B > 1 and L <= self.slot_len and 2 * L <= self.prefill_rows:
             # one pass over the weights for as many prompts as the activation workspace holds (all of them, normally): right-padded
             # to L rows each (causal attention keeps the padding inert); a larger request batch takes several such passes
             D = self.config.hidden_size
