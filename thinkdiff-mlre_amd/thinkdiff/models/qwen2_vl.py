@@ -346,6 +346,11 @@ class Qwen2VLTextEngine:
         key = None if forced_output_ids is not None else self._draw_sampler_key(generator)
         stops = set(sampling.stop_token_ids or [])
         step = 0
+        # per step: the hidden rows stay ONE device tensor and the slot -> request map is remembered; the rows are handed to their requests by a
+        # single gather after the loop (256 sequences x 256 steps of per-row tensor views and list appends were ~0.5 ms of host time per step,
+        # during which the GPU idled: 15 % of a 3.3 ms step)
+        step_hid, step_owner, step_toks = [], [], []
+        eos_on = (not sampling.ignore_eos) and eos_token_id is not None
         while owner and step < sampling.max_tokens:
             n = len(owner)
             if forced_output_ids is not None:
@@ -360,26 +365,37 @@ class Qwen2VLTextEngine:
             else:
                 # one launch for all live rows (td_sample_top_p_bf16); the ids come to the host once per step for the bookkeeping below
                 toks = _OPS.sample_top_p(logits[:n], float(sampling.temperature), float(sampling.top_p), int(key), int(step)).tolist()
-            pos = torch.tensor([[next_pos[i] for i in range(n)]] * 3, dtype=torch.int32)
+            pos = torch.tensor(next_pos[:n], dtype=torch.int32).unsqueeze(0).expand(3, n)
             hid, logits = self.decode_batch(toks, pos, cache_len[:n])
+            step_hid.append(hid)
+            step_owner.append(list(owner))
+            step_toks.append(toks)
+            may_stop = forced_output_ids is None and step + 1 >= sampling.min_tokens
             keep = []
             for i in range(n):
-                r = res[owner[i]]
-                r["token_ids"].append(toks[i])
-                r["hidden_states"].append(hid[i:i + 1])
                 cache_len[i] += 1
                 next_pos[i] += 1
-                done_eos = (not sampling.ignore_eos) and eos_token_id is not None and toks[i] == eos_token_id
-                stop = forced_output_ids is None and step + 1 >= sampling.min_tokens and (done_eos or toks[i] in stops)
+                stop = may_stop and ((eos_on and toks[i] == eos_token_id) or toks[i] in stops)
                 if not stop and cache_len[i] < self.slot_len:
                     keep.append(i)
             if len(keep) < n:
                 self._compact(owner, cache_len, next_pos, keep)
                 logits = logits[keep]
             step += 1
-        for r in res:
-            r["hidden_states"] = (torch.cat(r["hidden_states"]) if r["hidden_states"]
-                                  else torch.empty(0, self.config.hidden_size, dtype=torch.bfloat16, device=self.device))
+        rows = [[] for _ in range(B)]
+        base = 0
+        for owners, toks in zip(step_owner, step_toks):
+            for i, o in enumerate(owners):
+                rows[o].append(base + i)
+                res[o]["token_ids"].append(toks[i])
+            base += len(owners)
+        D = self.config.hidden_size
+        if base:
+            allh = torch.cat(step_hid)
+            idx = torch.tensor([r for rr in rows for r in rr], dtype=torch.int64).to(self.device)
+            parts = torch.split(allh.index_select(0, idx), [len(rr) for rr in rows])
+        for b, r in enumerate(res):
+            r["hidden_states"] = parts[b] if base and rows[b] else torch.empty(0, D, dtype=torch.bfloat16, device=self.device)
         return res
 
     def _compact(self, owner, cache_len, next_pos, keep):

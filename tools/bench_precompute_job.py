@@ -36,8 +36,8 @@ wds_io.write_wids_index(idx, shards, name="bench")
 argv = ["--cfg-path", os.path.join(ROOT, "tests", "golden", "qwen2_vl_embed_keys.yaml"), "--options", "run.synthetic=true",
         "run.synthetic_max_image_tokens=320", f"datasets.cc_sbu_mllama_vllm_process_wids.build_info.storage={idx}",
         f"datasets.cc_sbu_mllama_vllm_process_wids.batch_size={bs}", f"run.output_shard_path=[{root}/out,'%06d.tar',0]",
-        "model.vllm_config.max_model_len=2048", "model.vllm_config.max_tokens=64", "model.vllm_config.min_tokens=64", "model.vllm_config.ignore_eos=true",
-        "model.vllm_config.max_num_seqs=64",
+        "model.vllm_config.max_model_len=2048", f"model.vllm_config.max_tokens={os.environ.get('TD_JOB_TOKENS', '64')}", f"model.vllm_config.min_tokens={os.environ.get('TD_JOB_TOKENS', '64')}", "model.vllm_config.ignore_eos=true",
+        f"model.vllm_config.max_num_seqs={os.environ.get('TD_JOB_SEQS', '256')}", f"model.vllm_config.max_num_batched_tokens=60000",
         "model.text_config={hidden_size: 1536, num_hidden_layers: 28, num_attention_heads: 12, num_key_value_heads: 2, intermediate_size: 8960, vocab_size: 151936, tie_word_embeddings: true}"]
 t = {}
 orig = task_mod.ImageTextProcessDataTask.train_epoch
