@@ -10,7 +10,8 @@ properties (the judge's rule for full-size runs):
   * output_embed has one row per generated token, 1 <= n <= max_tokens, every value finite, rows are RMS-normalised (model.norm: mean square ~ |w|^2);
   * batched decode == one-sequence decode: for samples drawn from different chunks, teacher-forcing the tokens the job sampled through the
     one-sequence path (prefill + KV-cached steps, another kernel path) reproduces the stored hidden states to 4e-2 (two paths, each inside the engine's 2e-2 parity bar);
-  * a second run with the same seed writes byte-identical embeddings (the sampler is seeded by run.seed, as vLLM's is by `seed`).
+  * a second run with the same seed writes byte-identical embeddings (the sampler is seeded by run.seed, as vLLM's is by `seed`) -- the second run
+    with the request prefetch off, so the overlap of input processing and decoding is shown to change nothing.
 The multi-rank split of this job (shards by rank, disjoint output shard numbers, RCCL gather of counts) is covered on gloo by tests/test_precompute_cpu.py / test_dp_cpu.py.
 """
 import io
@@ -80,9 +81,13 @@ def test_precompute_job_full_size_qwen2vl_2b_shape(hip, tmp_path):
         runs = []
         for tag in ("a", "b"):
             out = tmp_path / f"emb_{tag}"
+            # run b builds every chunk's requests in line; run a builds chunk k + 1 on the helper thread / side stream while chunk k decodes
+            # (MllamaVllmGenerate_1.forward_inner): the byte-identity check below therefore also says that the overlap changes nothing
+            os.environ["TD_PRECOMPUTE_PREFETCH"] = "1" if tag == "a" else "0"
             res = job.main(common + [f"run.output_shard_path=[{out},'%06d.tar',0]"])
             runs.append(res[0] if isinstance(res, list) else res)
     finally:
+        os.environ.pop("TD_PRECOMPUTE_PREFETCH", None)
         task_mod.ImageTextProcessDataTask.train_epoch = orig
     stats = runs[0]
     assert stats["samples"] == N_SAMPLES
@@ -135,8 +140,8 @@ def test_precompute_job_full_size_qwen2vl_2b_shape(hip, tmp_path):
         # two bf16 paths with different tile shapes / summation orders through 28 layers, each within the engine's 2e-2 of the oracle
         # (tests/test_qwen2_gpu.py, tests/test_flux_full_depth_gpu.py::test_config3...): they may differ from each other by up to the sum
         assert e_i < 4e-2 and e_o < 4e-2, f"sample {k}: batched job vs one-sequence path: prompt {e_i:.4f}, output {e_o:.4f}"
-    rate = N_SAMPLES / min(timing["epoch"])
-    print(f"[config 4] {N_SAMPLES} samples, Qwen2-VL-2B shape, max_tokens 256: {rate:.1f} samples/s end to end (best of 2 runs: {timing['epoch']}), "
+    rate = N_SAMPLES / timing["epoch"][0]          # (run a: the shipped form, request prefetch on)
+    print(f"[config 4] {N_SAMPLES} samples, Qwen2-VL-2B shape, max_tokens 256: {rate:.1f} samples/s end to end (run a, prefetch on; run b, prefetch off: {timing['epoch']}), "
           f"generated tokens per sample {min(n_out)}..{max(n_out)}; batched vs one-sequence rel-RMSE (prompt, output) {errs}")
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)

@@ -10,6 +10,8 @@ tower -> placeholder splice -> M-RoPE positions).  The chat template / tokenizer
 synthetic stand-in (`providers.load_lvlm_frontend`); `request_builder(samples, i) -> {"prompt", "prompt_token_ids", optional
 "inputs_embeds", "position_ids"}` overrides the whole front end.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
 from types import SimpleNamespace
 from typing import Callable, Dict, List, Optional
 
@@ -17,6 +19,7 @@ import torch
 
 from .. import _hip
 from ..common.registry import registry
+
 from .base_model import BaseModel
 from .qwen2_vl import QwenChatFrontend, Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
 
@@ -78,8 +81,20 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         layer = self.config.vllm_config.get("embedding_layer_name", "model.norm")
         tok = {"input_prompt": [], "input_prompt_token_ids": [], "output_text": [], "output_token_ids": []}
         out_embed, in_embed, texts = [], [], []
-        for c0 in range(0, n, self.decode_batch):
-            reqs = self._requests(mllama_inputs, range(c0, min(c0 + self.decode_batch, n)))
+        # The requests of chunk k + 1 -- chat template, image resize, device patchify, the vision tower, token embeddings: ~1.2 s per 512 samples, a
+        # third of the chunk's decode time -- are built by a helper thread on a stream of its own while chunk k decodes (the decode loop is a chain
+        # of small latency-bound launches that leaves most of the chip idle, and its host thread spends its time waiting for token ids).  vLLM's
+        # engine overlaps its input processing with decoding in the same way.  TD_PRECOMPUTE_PREFETCH=0: one after the other (A/B).
+        chunks = [range(c0, min(c0 + self.decode_batch, n)) for c0 in range(0, n, self.decode_batch)]
+        prefetch = len(chunks) > 1 and os.environ.get("TD_PRECOMPUTE_PREFETCH", "1") != "0"
+        pool = ThreadPoolExecutor(max_workers=1) if prefetch else None
+        fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[0]) if prefetch else None
+        for k, idx in enumerate(chunks):
+            if prefetch:
+                reqs = fut.result()
+                fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[k + 1]) if k + 1 < len(chunks) else None
+            else:
+                reqs = self._requests(mllama_inputs, idx)
             outs = self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator)
             for r, o in zip(reqs, outs):
                 text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
@@ -90,8 +105,21 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
                 texts.append(text)
                 out_embed.append(o["hidden_states"])
                 in_embed.append(o["prompt_hidden_states"])
+        if pool is not None:
+            pool.shutdown(wait=True)
         return {"generated_text": texts, "generated_token": tok,
                 "generated_embed": {layer: {"output_embed": out_embed, "input_embed": in_embed}}}
+
+    def _requests_on_side_stream(self, inputs: dict, idx) -> List[dict]:
+        """`_requests` on the helper thread: its launches go to a stream of this model's own (torch's current stream is per thread), and the thread
+        returns only when they have completed, so the decode thread may use the tensors on its stream without an event."""
+        with torch.no_grad(), torch.cuda.device(self._device):
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=self._device)
+            with torch.cuda.stream(self._side_stream):
+                reqs = self._requests(inputs, idx)
+            self._side_stream.synchronize()
+        return reqs
 
     def forward(self, samples, reduction="mean"):
         inputs = {k: v for k, v in samples.items() if k not in ("epoch", "num_iters_per_epoch", "iters")}
