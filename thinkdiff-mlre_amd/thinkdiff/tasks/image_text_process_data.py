@@ -67,9 +67,15 @@ class ImageTextProcessDataTask(BaseTask):
                     writer.write(enc)
 
             pending = None
+            import time
+            timing = os.environ.get("TD_PRECOMPUTE_TIMING") is not None      # where a batch's wall time goes: loader wait | model | host copies | writer wait
+            t_load = t_model = t_host = t_wait = 0.0
+            t_mark = time.perf_counter()
             for samples in data_loader:
+                t0 = time.perf_counter(); t_load += t0 - t_mark
                 batch = len(samples["images"])
                 output = model(samples)
+                t1 = time.perf_counter(); t_model += t1 - t0
                 embeds = flatten_dict(output["generated_embed"]) if output.get("generated_embed") is not None else None
                 host = {}
                 if embeds is not None:
@@ -89,12 +95,19 @@ class ImageTextProcessDataTask(BaseTask):
                     for k, v in host.items():
                         rec[f"{k}.pth"] = _CompactTensor(v[i])
                     records.append(rec)
+                t2 = time.perf_counter(); t_host += t2 - t1
                 if pending is not None:
                     pending.result()                 # at most one batch of records in flight behind the model
                 pending = tar_thread.submit(write_batch, records)
                 n_written += batch
+                t_mark = time.perf_counter(); t_wait += t_mark - t2
+            t2 = time.perf_counter()
             if pending is not None:
                 pending.result()
+            t_wait += time.perf_counter() - t2
+            if timing:
+                print(f"[precompute timing] {n_written} samples: loader wait {t_load:.2f} s, model {t_model:.2f} s, device->host + records {t_host:.2f} s, "
+                      f"writer wait {t_wait:.2f} s", flush=True)
         return {"samples": n_written, "shards": writer.shards}
 
     def train_epoch(self, epoch, model, data_loader, output_shard_path=None, **kw):
