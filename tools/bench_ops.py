@@ -369,6 +369,26 @@ def bench_pack8():
           f"v {1e3*(res[0]-res[1]):.1f} + k {1e3*(res[0]-res[2]):.1f} + q {1e3*(res[0]-res[4]):.1f} (+ fixed {1e3*(res[1]+res[2]+res[4]-2*res[0]-base):.1f})", flush=True)
 
 
+def bench_norm():
+    """td_norm_rows_kernel<6> at the denoise loop's shape: LayerNorm + adaLN modulate of the joint [text | image] rows (S = 4354, D = 3072), bf16 out and
+    int8 out, rotating over six inputs larger than the caches.  Rows per wave come from TD_NORM_ROWS_PER_WAVE (read once per process)."""
+    S, D = 4354, 3072
+    pool = [torch.randn(S, D, device="cuda").bfloat16() for _ in range(6)]
+    mods = [torch.randn(D, device="cuda").bfloat16() * 0.1 for _ in range(4)]
+    out = torch.empty(S, D, device="cuda", dtype=torch.bfloat16)
+    st = {"i": 0}
+    def f():
+        st["i"] = (st["i"] + 1) % len(pool)
+        _hip.norm_rows(pool[st["i"]], out=out, eps=1e-6, split=258, shiftA=mods[0], scaleA=mods[1], shiftB=mods[2], scaleB=mods[3])
+    def g():
+        st["i"] = (st["i"] + 1) % len(pool)
+        _hip.norm_rows_quant_fp8(pool[st["i"]], eps=1e-6, split=258, shiftA=mods[0], scaleA=mods[1], shiftB=mods[2], scaleB=mods[3])
+    best = min(timeit(f, iters=50, warmup=5) for _ in range(3))
+    bq = min(timeit(g, iters=50, warmup=5) for _ in range(3))
+    print(f"norm rows S={S} D={D} rows/wave={os.environ.get('TD_NORM_ROWS_PER_WAVE', 'auto')}: bf16 out {best*1e3:.1f} us = {2*S*D*2/best/1e9:.2f} TB/s; "
+          f"8-bit out {bq*1e3:.1f} us", flush=True)
+
+
 def bench_gemmref():
     """External yardstick for the block GEMMs (measurement only; never in the product): torch.nn.functional.linear (= hipBLASLt on
     this image) against td_linear on the six FLUX.1-dev block shapes at the joint sequence length, random operands, same box, same
