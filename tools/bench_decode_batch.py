@@ -14,11 +14,11 @@ if group:
     _hip.lib().td_attention_decode_set_group(group[0])
 which = [a for a in sys.argv[1:] if not a.isdigit() and not a.startswith("G=")] or ["2B", "7B"]
 batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 4, 8, 16, 24, 32, 48, 64]
-CACHE = 300
+CACHE = int(os.environ.get("TD_BENCH_CACHE", "300"))
 for name in which:
     cfg = shapes[name]
     slots = max(64, max(batches))
-    e = Qwen2VLTextEngine(cfg, max_model_len=512, n_slots=slots, prefill_rows=64 * 320).init_random(0)
+    e = Qwen2VLTextEngine(cfg, max_model_len=max(512, (CACHE + 64 + 63) // 64 * 64), n_slots=slots, prefill_rows=64 * 320).init_random(0)
     wbytes = 2 * (cfg.num_hidden_layers * (cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * 128 + cfg.num_attention_heads * 128 * cfg.hidden_size
                   + 3 * cfg.hidden_size * cfg.intermediate_size) + cfg.vocab_size * cfg.hidden_size)
     for B in batches:
