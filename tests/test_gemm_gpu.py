@@ -332,3 +332,21 @@ def test_linear_split_k_with_fused_rmsnorm(hip, M, N, K):
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and torch.equal(n0, n1)
     _close(y1, _ref_linear(x.cpu(), w.cpu(), res=r.cpu()))
+
+
+@pytest.mark.parametrize("M", [17, 33, 64, 65])
+def test_linear_split_k_small_m_boundaries(hip, M):
+    """The planner's lower edge: 16 < M <= 64 asked for with split_k = -1 takes the tile kernels (a caller that sets split_k wants them), M = 65 is
+    the first wide decode step; all against fp32 math, with and without the fused RMSNorm."""
+    g = torch.Generator().manual_seed(M)
+    N, K = 1536, 4096
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    nw = (1.0 + 0.1 * torch.randn(N, generator=g)).bfloat16().cuda()
+    y = hip.linear_splitk(x, w, b)
+    n1 = torch.empty_like(y)
+    y1 = hip.linear_splitk(x, w, b, norm_w=nw, norm_out=n1)
+    torch.cuda.synchronize()
+    _close(y, _ref_linear(x.cpu(), w.cpu(), b.cpu()))
+    assert torch.equal(y, y1) and torch.equal(n1, hip.norm_rows(y, rms=True, eps=1e-6, w=nw))

@@ -433,3 +433,41 @@ def test_packed_prefill_equals_padded_and_single(hip):
     for r, o in zip(reqs[1:5], gb):
         ref = e.generate(r["prompt_token_ids"], sp0, position_ids=r.get("position_ids"))
         assert o["token_ids"] == ref["token_ids"]
+
+
+def test_packed_prefill_from_token_ids_through_the_c_abi(hip):
+    """td_qwen2_prefill_packed with token ids instead of embeddings (the form a C caller uses), one and several prompts, logits of the last tokens: against
+    td_qwen2_forward_slot per prompt -- bit-equal (same kernels per row: the packed form only changes which rows share a launch)."""
+    import ctypes
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=19)
+    tc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                           intermediate_size=cfg.intermediate, vocab_size=cfg.vocab, tie_word_embeddings=cfg.tie_embeddings)
+    e = Qwen2VLTextEngine(tc, max_model_len=256, n_slots=4, prefill_rows=1024)
+    e.load_state_dict(sd)
+    L = hip.lib()
+    g = torch.Generator().manual_seed(2)
+    for lens in ([70], [1, 255, 64, 33]):
+        ids = [torch.randint(0, cfg.vocab, (n,), generator=g).to(torch.int32) for n in lens]
+        total = sum(lens)
+        tok = torch.cat(ids).cuda().contiguous()
+        pos = torch.cat([e.text_position_ids(n) for n in lens], dim=1).to(torch.int32).cuda().contiguous()
+        hid = torch.empty(total, cfg.hidden, dtype=torch.bfloat16, device="cuda")
+        lg = torch.empty(len(lens), cfg.vocab, dtype=torch.bfloat16, device="cuda")
+        cl = (ctypes.c_int * len(lens))(*lens)
+        hip.check(L.td_qwen2_prefill_packed(e._h, 0, len(lens), hip.ptr(tok), None, hip.ptr(pos), ctypes.cast(cl, ctypes.c_void_p), hip.ptr(hid), hip.ptr(lg), hip.stream_ptr()))
+        torch.cuda.synchronize()
+        r = 0
+        for b, n in enumerate(lens):
+            h1, l1 = e.forward(e.text_position_ids(n), ids[b], want_hidden=True, want_logits=True, slot=b)
+            torch.cuda.synchronize()
+            assert _rel(hid[r:r + n], h1) < 5e-3 and _rel(lg[b], l1) < 5e-3
+            r += n
+    # refused: more rows than the workspace, a prompt longer than its slot
+    big = (ctypes.c_int * 4)(255, 255, 255, 255)
+    hip.check(L.td_qwen2_prefill_packed(e._h, 0, 4, hip.ptr(torch.zeros(1020, dtype=torch.int32, device="cuda")), None,
+                                        hip.ptr(torch.zeros(3, 1020, dtype=torch.int32, device="cuda")), ctypes.cast(big, ctypes.c_void_p), None, None, hip.stream_ptr()))
+    with pytest.raises(hip.ThinkDiffHipError):
+        bad = (ctypes.c_int * 1)(300)
+        hip.check(L.td_qwen2_prefill_packed(e._h, 0, 1, hip.ptr(tok), None, hip.ptr(pos), ctypes.cast(bad, ctypes.c_void_p), None, None, hip.stream_ptr()))
