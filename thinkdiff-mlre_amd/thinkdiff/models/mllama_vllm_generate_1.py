@@ -89,24 +89,26 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         prefetch = len(chunks) > 1 and os.environ.get("TD_PRECOMPUTE_PREFETCH", "1") != "0"
         pool = ThreadPoolExecutor(max_workers=1) if prefetch else None
         fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[0]) if prefetch else None
-        for k, idx in enumerate(chunks):
-            if prefetch:
-                reqs = fut.result()
-                fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[k + 1]) if k + 1 < len(chunks) else None
-            else:
-                reqs = self._requests(mllama_inputs, idx)
-            outs = self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator)
-            for r, o in zip(reqs, outs):
-                text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
-                tok["input_prompt"].append(r.get("prompt", ""))
-                tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
-                tok["output_text"].append(text)
-                tok["output_token_ids"].append(tuple(o["token_ids"]))
-                texts.append(text)
-                out_embed.append(o["hidden_states"])
-                in_embed.append(o["prompt_hidden_states"])
-        if pool is not None:
-            pool.shutdown(wait=True)
+        try:
+            for k, idx in enumerate(chunks):
+                if prefetch:
+                    reqs = fut.result()
+                    fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[k + 1]) if k + 1 < len(chunks) else None
+                else:
+                    reqs = self._requests(mllama_inputs, idx)
+                outs = self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator)
+                for r, o in zip(reqs, outs):
+                    text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
+                    tok["input_prompt"].append(r.get("prompt", ""))
+                    tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
+                    tok["output_text"].append(text)
+                    tok["output_token_ids"].append(tuple(o["token_ids"]))
+                    texts.append(text)
+                    out_embed.append(o["hidden_states"])
+                    in_embed.append(o["prompt_hidden_states"])
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)      # (also when a chunk raised: the helper thread does not outlive the call)
         return {"generated_text": texts, "generated_token": tok,
                 "generated_embed": {layer: {"output_embed": out_embed, "input_embed": in_embed}}}
 
