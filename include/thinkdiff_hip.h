@@ -414,6 +414,9 @@ int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* t
  * logits_last bf16[B, vocab] of each prompt's last token (either output may be NULL). */
 int td_qwen2_prefill_packed(td_qwen2* f, int slot0, int B, const int* token_ids, const void* inputs_embeds, const int* position_ids,
                             const int* lens, void* hidden_out, void* logits_last, void* stream);
+/* ... sequence b into cache slot slots[b] (HOST ints, distinct, any order): the free slots of a running batch (continuous batching). */
+int td_qwen2_prefill_packed_slots(td_qwen2* f, int B, const int* slots, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                                  const int* lens, void* hidden_out, void* logits_last, void* stream);
 int td_qwen2_set_slots(td_qwen2* f, int n_slots);   /* re-partition the cache rows of an existing handle */
 /* Decode step: the rotary embedding of the new q / k rows and the write of the new k | v rows into the cache happen inside the decode-attention
  * launch (default, one launch per layer fewer) or in a launch of their own (on = 0: A/B and the bit-identity test).  Same arithmetic either way
@@ -427,6 +430,12 @@ int td_qwen2_move_slot(td_qwen2* f, int src, int dst, int len, void* stream);
  * logits bf16[B,vocab] (either may be NULL). */
 int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
                           void* hidden_out, void* logits, void* stream);
+/* td_qwen2_decode_batch for the sequences in cache slots slots[0 .. B-1] (HOST ints, distinct; NULL = 0 .. B-1); row b of token_ids / position_ids /
+ * cache_pos / hidden_out / logits belongs to slot slots[b].  A finished sequence then frees its slot without any cache rows being moved and a waiting
+ * request is prefilled into it (td_qwen2_prefill_packed_slots): vLLM's continuous batching of the reference's request batches
+ * (thinkdiff/models/mllama_vllm_generate_1.py:585, `max_num_seqs: 256`), with whole-sequence slots in place of paged blocks. */
+int td_qwen2_decode_batch_slots(td_qwen2* f, int B, const int* slots, const int* token_ids, const int* position_ids, const int* cache_pos,
+                                void* hidden_out, void* logits, void* stream);
 /* out bf16[n,hidden] = embed_tokens[token_ids] (device int32[n]): the host splices vision tokens into this to form inputs_embeds. */
 int td_qwen2_embed_tokens(td_qwen2* f, const int* token_ids, void* out, int n, void* stream);
 

@@ -471,3 +471,74 @@ def test_packed_prefill_from_token_ids_through_the_c_abi(hip):
     with pytest.raises(hip.ThinkDiffHipError):
         bad = (ctypes.c_int * 1)(300)
         hip.check(L.td_qwen2_prefill_packed(e._h, 0, 1, hip.ptr(tok), None, hip.ptr(pos), ctypes.cast(bad, ctypes.c_void_p), None, None, hip.stream_ptr()))
+
+
+def test_continuous_batching_equals_one_request_at_a_time(hip):
+    """generate_continuous: 45 requests against 8 cache slots -- a finished sequence's slot goes to a waiting request (compaction + one packed prefill
+    pass into the free slots), requests arriving in chunks from an iterable.  Teacher-forced outputs of 0..14 tokens (so slots free up at different
+    steps, several admissions, a request with nothing to generate), one request with distinct M-RoPE streams and one with its own embeddings:
+    prompt states, output states and token ids against generate() per request; then sampled continuation: reproducible under a seed, every
+    request gets max_tokens tokens, and greedy sampling equals the one-request path."""
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine, SamplingParams
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=23)
+    tc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                           intermediate_size=cfg.intermediate, vocab_size=cfg.vocab, tie_word_embeddings=cfg.tie_embeddings)
+    g = torch.Generator().manual_seed(12)
+    N = 45
+    lens = [1 + (17 * i) % 90 for i in range(N)]
+    gens = [(5 * i + 3) % 15 for i in range(N)]
+    gens[7] = 0
+    reqs = [{"prompt_token_ids": torch.randint(0, cfg.vocab, (n,), generator=g).tolist()} for n in lens]
+    reqs[11]["position_ids"] = torch.stack([torch.arange(lens[11]), torch.arange(lens[11]) // 3 + 2, (torch.arange(lens[11]) * 2) % 11]).to(torch.int32)
+    forced = [torch.randint(0, cfg.vocab, (k,), generator=g).tolist() for k in gens]
+    sp = SamplingParams(max_tokens=14, min_tokens=14, ignore_eos=True)
+    e1 = Qwen2VLTextEngine(tc, max_model_len=128)
+    e1.load_state_dict(sd)
+    single = []
+    for r, f in zip(reqs, forced):
+        o = e1.generate(r["prompt_token_ids"], SamplingParams(max_tokens=max(len(f), 1), min_tokens=len(f), ignore_eos=True), position_ids=r.get("position_ids"),
+                        forced_output_ids=f) if f else {"prompt_hidden_states": e1.forward(e1.text_position_ids(len(r["prompt_token_ids"])),
+                                                                                         torch.tensor(r["prompt_token_ids"], dtype=torch.int32))[0],
+                                                      "hidden_states": torch.empty(0, cfg.hidden, dtype=torch.bfloat16, device="cuda"), "token_ids": []}
+        single.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    e = Qwen2VLTextEngine(tc, max_model_len=128, n_slots=8, prefill_rows=300)
+    e.load_state_dict(sd)
+    rr = [dict(r) for r in reqs]
+    rr[20]["inputs_embeds"] = e.embed_tokens(rr[20]["prompt_token_ids"])
+    chunks = [rr[0:10], rr[10:11], rr[11:30], rr[30:45]]
+    out = e.generate_continuous(iter(chunks), sp, forced_output_ids=forced, admit_min=2)
+    torch.cuda.synchronize()
+    assert len(out) == N
+    for a, b, k, n in zip(single, out, gens, lens):
+        assert b["token_ids"] == a["token_ids"] and b["hidden_states"].shape == (k, cfg.hidden) and b["prompt_hidden_states"].shape == (n, cfg.hidden)
+        assert _rel(b["prompt_hidden_states"], a["prompt_hidden_states"]) < 5e-3
+        if k:
+            assert _rel(b["hidden_states"], a["hidden_states"]) < 5e-3
+    # sampled: reproducible, complete, and (greedy) equal to the one-request path
+    sps = SamplingParams(temperature=0.8, top_p=0.9, max_tokens=9, min_tokens=9, ignore_eos=True)
+    runs = []
+    for _ in range(2):
+        gg = torch.Generator(device="cuda").manual_seed(5)
+        o = e.generate_continuous([dict(r) for r in reqs[:30]], sps, generator=gg)
+        runs.append([x["token_ids"] for x in o])
+    assert runs[0] == runs[1] and all(len(t) == 9 for t in runs[0])
+    # greedy: every sampled token is the arg-max of ITS sequence's logits -- checked against lm_head applied to the hidden state the call returned for
+    # that sequence and step (a logits row attached to the wrong slot after a compaction or an admission would pick a token far below the maximum;
+    # a one-ulp tie between the 8-row and the 1-row Linear kernels may not flip the test, hence "within a bf16 ulp of the maximum")
+    W = (sd["model.embed_tokens.weight"] if cfg.tie_embeddings else sd["lm_head.weight"]).float().cuda()
+    def near_argmax(state, tok):
+        ref = state.float() @ W.t()
+        return float(ref[tok]) >= float(ref.max()) - 2.0 ** -6 * float(ref.abs().max())
+    sp0 = SamplingParams(temperature=0.0, max_tokens=12, min_tokens=1, ignore_eos=True, stop_token_ids=list(range(0, cfg.vocab, 5)))
+    o = e.generate_continuous([dict(r) for r in reqs[:30]], sp0)
+    n_tok = []
+    for r, x in zip(reqs[:30], o):
+        t = x["token_ids"]
+        n_tok.append(len(t))
+        assert 1 <= len(t) <= 12 and x["hidden_states"].shape[0] == len(t)
+        assert all(tt % 5 != 0 for tt in t[:-1]) and (len(t) == 12 or t[-1] % 5 == 0)          # stopped exactly at its first stop token
+        assert near_argmax(x["prompt_hidden_states"][-1], t[0])
+        for k in range(len(t) - 1):
+            assert near_argmax(x["hidden_states"][k], t[k + 1])
+    assert len(set(n_tok)) > 2, "the stop tokens end the sequences at different steps (slots are re-used mid-flight)"

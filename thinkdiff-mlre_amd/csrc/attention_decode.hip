@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void td_attn_decode_kernel(const TdAttnParams 
   const int j = lane & 15;                       // 16-B chunk of the 256-B head row
   const int slot = wid * 4 + (lane >> 4);        // key slot 0..15
   const int len = p.kv_lens ? p.kv_lens[b] : p.Skv;
-  const bf16_t* Kb = p.K + (size_t)b * p.kv_bstride + (size_t)kvh * 128 + 8 * j;
-  const bf16_t* Vb = p.V + (size_t)b * p.kv_bstride + (size_t)kvh * 128 + 8 * j;
+  const int cslot = p.dec_slots ? p.dec_slots[b] : b;      // the cache slot of sequence b
+  const bf16_t* Kb = p.K + (size_t)cslot * p.kv_bstride + (size_t)kvh * 128 + 8 * j;
+  const bf16_t* Vb = p.V + (size_t)cslot * p.kv_bstride + (size_t)kvh * 128 + 8 * j;
   const bf16_t* Qb = p.Q + (size_t)b * p.q_bstride + (size_t)qg * G * 128 + 8 * j;
   u32x4_t q[G];
 #pragma unroll

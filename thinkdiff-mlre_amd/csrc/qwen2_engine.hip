@@ -85,7 +85,7 @@ constexpr int MAX_BATCH = 256;
 constexpr int STREAM_BATCH = 64;
 constexpr int64_t SK_WS_BYTES = 32ll << 20;
 
-struct IntPack { int v[2 * MAX_BATCH]; };
+struct IntPack { int v[3 * MAX_BATCH]; };      // (3 KB of kernel arguments: lengths | cache rows | cache slots of a decode step)
 __global__ void td_set_ints_kernel(int* dst, IntPack vals, int n) {
   if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
 }
@@ -230,7 +230,7 @@ int td_qwen2_create_ex(const TdQwen2Config* cfg, int slot_len, int n_slots, int 
       {(void**)&f->h, n * D * 2}, {(void**)&f->xn, n * D * 2}, {(void**)&f->q, n * Hq * 128 * 2},
       {(void**)&f->attn, n * Hq * 128 * 2}, {(void**)&f->gu, n * 2 * I * 2}, {(void**)&f->act, n * I * 2},
       {(void**)&f->cosT, n * 128 * 4}, {(void**)&f->sinT, n * 128 * 4},
-      {(void**)&f->kvtmp, n * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, 4 * MAX_BATCH * 4}, {(void**)&f->lastrows, (int64_t)MAX_BATCH * D * 2},
+      {(void**)&f->kvtmp, n * 2 * Hkv * 128 * 2}, {(void**)&f->ibuf, (5 * MAX_BATCH + 16) * 4}, {(void**)&f->lastrows, (int64_t)MAX_BATCH * D * 2},
       {(void**)&f->tok_buf, MAX_BATCH * 4}, {(void**)&f->pos_buf, 3 * MAX_BATCH * 4}, {(void**)&f->logits_buf, (int64_t)MAX_BATCH * cfg->vocab * 2},
       {(void**)&f->sk_ws, SK_WS_BYTES}, {(void**)&f->row_map, n * 4},
   };
@@ -441,6 +441,7 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
   const int QW = Hq * 128, KVW = 2 * Hkv * 128;
   const int* kv_lens = f->ibuf;
   const int* row_off = f->ibuf + MAX_BATCH;
+  const int* slot_ids = f->ibuf + 2 * MAX_BATCH;      // cache slot of each sequence of the step
   // Cross-over between the weight-stream kernels and the tile kernels, measured on both decoder shapes (profiles/r4z_decode_crossover.log): the 2B
   // shape (hidden 1536) stays ahead on the stream through 64 sequences (2.68 vs 2.79 ms per step), the 7B shape (hidden 3584) is level at 24 and
   // 18 % ahead on the tiles at 64 (5.44 vs 6.63 ms).  TD_QWEN2_STREAM_BATCH (>= 16): A/B.
@@ -476,7 +477,7 @@ int decode_step(td_qwen2* f, int B, int max_len, bool want_logits, hipStream_t s
     ap.Q = f->q; ap.ldq = QW; ap.q_bstride = QW; ap.K = l.kv; ap.V = l.kv + Hkv * 128; ap.ldkv = KVW;
     ap.kv_bstride = (long long)f->slot_len * KVW; ap.O = f->attn; ap.ldo = QW; ap.o_bstride = QW;
     ap.batch = B; ap.Sq = 1; ap.Skv = max_len; ap.Hq = Hq; ap.Hkv = Hkv; ap.scale = 0.08838834764831845f;
-    ap.causal = 1; ap.causal_offset = max_len - 1; ap.kv_lens = kv_lens;
+    ap.causal = 1; ap.causal_offset = max_len - 1; ap.kv_lens = kv_lens; ap.dec_slots = slot_ids;
     TDQ_TRY(td_attn_launch(ap, s));
     {
       TdGemmParams g;
@@ -532,6 +533,14 @@ extern "C" {
 // cache_pos[b] = tokens already in slot b (HOST ints).  hidden_out bf16[B,hidden], logits bf16[B,vocab] (either may be NULL).
 int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* position_ids, const int* cache_pos,
                           void* hidden_out, void* logits, void* stream) {
+  return td_qwen2_decode_batch_slots(f, B, nullptr, token_ids, position_ids, cache_pos, hidden_out, logits, stream);
+}
+
+// ... for the sequences in cache slots slots[0 .. B-1] (HOST ints, distinct; NULL = 0 .. B-1): row b of the inputs and outputs belongs to slot slots[b].
+// A finished sequence frees its slot with no cache rows moved, a new one is prefilled into any free slot (td_qwen2_prefill_packed_slots): the
+// bookkeeping of continuous batching ([ext] vLLM's block tables, reduced to whole-sequence slots: 256 x 8192 rows fit the HBM outright).
+int td_qwen2_decode_batch_slots(td_qwen2* f, int B, const int* slots, const int* token_ids, const int* position_ids, const int* cache_pos,
+                                void* hidden_out, void* logits, void* stream) {
   TD_CHECK_ARG(f && token_ids && position_ids && cache_pos, "td_qwen2_decode_batch: null argument");
   TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH && B <= f->n_slots && B <= f->ws_rows, "td_qwen2_decode_batch: batch %d exceeds min(%d, %d slots, %d workspace rows)", B, MAX_BATCH, f->n_slots, f->ws_rows);
   hipStream_t s = (hipStream_t)stream;
@@ -539,12 +548,15 @@ int td_qwen2_decode_batch(td_qwen2* f, int B, const int* token_ids, const int* p
   IntPack ip;
   int max_len = 0;
   for (int b = 0; b < B; ++b) {
+    const int slot = slots ? slots[b] : b;
+    TD_CHECK_ARG(slot >= 0 && slot < f->n_slots, "td_qwen2_decode_batch: sequence %d names cache slot %d of %d", b, slot, f->n_slots);
     TD_CHECK_ARG(cache_pos[b] >= 0 && cache_pos[b] < f->slot_len, "td_qwen2_decode_batch: sequence %d is full (%d of %d)", b, cache_pos[b], f->slot_len);
     ip.v[b] = cache_pos[b] + 1;                                         // keys visible to the new token
-    ip.v[MAX_BATCH + b] = b * f->slot_len + cache_pos[b];               // its cache row (index; the kernels scale it by the row width)
+    ip.v[MAX_BATCH + b] = slot * f->slot_len + cache_pos[b];            // its cache row (index; the kernels scale it by the row width)
+    ip.v[2 * MAX_BATCH + b] = slot;
     max_len = cache_pos[b] + 1 > max_len ? cache_pos[b] + 1 : max_len;
   }
-  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, f->ibuf, ip, 2 * MAX_BATCH);
+  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(3 * MAX_BATCH), 0, s, f->ibuf, ip, 3 * MAX_BATCH);
   TD_CHECK_LAUNCH();
   // the step reads its ids from fixed buffers and leaves its outputs in fixed buffers (the captured form needs stable addresses)
   TD_CHECK_HIP(hipMemcpyAsync(f->tok_buf, token_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
@@ -679,8 +691,18 @@ int td_qwen2_prefill_batch_at(td_qwen2* f, int slot0, int B, int L, const int* t
 // int32[3, total]; hidden_out bf16[total, hidden]; logits_last bf16[B, vocab] of each prompt's last token (either output may be NULL).
 int td_qwen2_prefill_packed(td_qwen2* f, int slot0, int B, const int* token_ids, const void* inputs_embeds, const int* position_ids,
                             const int* lens, void* hidden_out, void* logits_last, void* stream) {
-  TD_CHECK_ARG(f && position_ids && lens && (token_ids || inputs_embeds), "td_qwen2_prefill_packed: null argument");
-  TD_CHECK_ARG(slot0 >= 0 && B >= 1 && B <= MAX_BATCH && slot0 + B <= f->n_slots, "td_qwen2_prefill_packed: slots [%d, %d) exceed the handle's %d", slot0, slot0 + B, f->n_slots);
+  TD_CHECK_ARG(slot0 >= 0 && B >= 1 && B <= MAX_BATCH, "td_qwen2_prefill_packed: bad slot range");
+  int slots[MAX_BATCH];
+  for (int b = 0; b < B; ++b) slots[b] = slot0 + b;
+  return td_qwen2_prefill_packed_slots(f, B, slots, token_ids, inputs_embeds, position_ids, lens, hidden_out, logits_last, stream);
+}
+
+// ... sequence b into cache slot slots[b] (HOST ints, distinct, any order): the free slots of a running batch
+int td_qwen2_prefill_packed_slots(td_qwen2* f, int B, const int* slots, const int* token_ids, const void* inputs_embeds, const int* position_ids,
+                                  const int* lens, void* hidden_out, void* logits_last, void* stream) {
+  TD_CHECK_ARG(f && slots && position_ids && lens && (token_ids || inputs_embeds), "td_qwen2_prefill_packed: null argument");
+  TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH, "td_qwen2_prefill_packed: %d sequences (1 .. %d)", B, MAX_BATCH);
+  for (int b = 0; b < B; ++b) TD_CHECK_ARG(slots[b] >= 0 && slots[b] < f->n_slots, "td_qwen2_prefill_packed: sequence %d names cache slot %d of %d", b, slots[b], f->n_slots);
   long long total = 0;
   int L = 0;
   for (int b = 0; b < B; ++b) {
@@ -694,17 +716,17 @@ int td_qwen2_prefill_packed(td_qwen2* f, int slot0, int B, const int* token_ids,
   const int QW = Hq * 128, KVW = 2 * Hkv * 128, n = (int)total;
   // segment starts (device, for the attention and the last-row gather) and the cache row of every packed row
   IntPack ip;
-  int* seg_starts = f->ibuf + 2 * MAX_BATCH;      // [B + 1] behind the decode step's lengths and rows
-  static_assert(MAX_BATCH + 1 <= 2 * MAX_BATCH, "seg_starts fit one IntPack");
+  int* seg_starts = f->ibuf + 3 * MAX_BATCH;      // [B + 1] behind the decode step's lengths, rows and slots
+  static_assert(MAX_BATCH + 1 <= 3 * MAX_BATCH, "seg_starts fit one IntPack");
   f->row_map_host.resize((size_t)n);
   int r = 0;
   for (int b = 0; b < B; ++b) {
     ip.v[b] = r;
-    for (int t = 0; t < lens[b]; ++t) f->row_map_host[(size_t)r + t] = (slot0 + b) * f->slot_len + t;
+    for (int t = 0; t < lens[b]; ++t) f->row_map_host[(size_t)r + t] = slots[b] * f->slot_len + t;
     r += lens[b];
   }
   ip.v[B] = r;
-  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(2 * MAX_BATCH), 0, s, seg_starts, ip, B + 1);
+  hipLaunchKernelGGL(td_set_ints_kernel, dim3(1), dim3(3 * MAX_BATCH), 0, s, seg_starts, ip, B + 1);
   TD_CHECK_LAUNCH();
   TD_CHECK_HIP(hipMemcpyAsync(f->row_map, f->row_map_host.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
   if (inputs_embeds) TD_CHECK_HIP(hipMemcpyAsync(f->h, inputs_embeds, (size_t)n * D * 2, hipMemcpyDeviceToDevice, s));

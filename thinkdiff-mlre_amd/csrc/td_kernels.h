@@ -98,6 +98,9 @@ struct TdAttnParams {
   // itself (rotate_half, every product rounded to bf16: td_decode_rope_scatter_kernel's arithmetic), uses the new key / value as the last of its
   // kv_lens[b] keys from registers, and the first workgroup of each kv head writes them to the cache -- nobody reads that row in this launch.
   const bf16_t* dec_kv_new = nullptr; const float* dec_cos = nullptr; const float* dec_sin = nullptr; const int* dec_row_off = nullptr;
+  // decode kernel only: sequence b's cache is slot dec_slots[b] (K / V + dec_slots[b] kv_bstride) instead of slot b -- the sequences of a step need not
+  // sit in the first slots, so a finished sequence frees its slot without anybody's cache rows being moved (continuous batching); q / o stay row b
+  const int* dec_slots = nullptr;
   // optional packed segments (device int[batch + 1], non-causal): segment b = rows [seg_starts[b], seg_starts[b+1]) of q/k/v/o; Sq = Skv = the longest
   const int* seg_starts = nullptr;
   // optional hand-off workspace of the persistent (stream-K) joint-attention kernel: td_attn_streamk_ws_bytes() bytes, zeroed

@@ -117,9 +117,11 @@ def _declare(L):
         "td_qwen2_prefill_batch": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
         "td_qwen2_prefill_batch_at": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
         "td_qwen2_prefill_packed": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+        "td_qwen2_prefill_packed_slots": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
         "td_qwen2_slot_capacity": [vp],
         "td_qwen2_move_slot": [vp, i32, i32, i32, vp],
         "td_qwen2_decode_batch": [vp, i32, vp, vp, vp, vp, vp, vp],
+        "td_qwen2_decode_batch_slots": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
         "td_embed_gather_bf16": [vp, vp, vp, i32, i32, i32, vp],
         "td_silu_mul_bf16": [vp, vp, i32, i32, vp],
         "td_mrope_table": [vp, i32, vp, f32, i32, vp, vp, vp],

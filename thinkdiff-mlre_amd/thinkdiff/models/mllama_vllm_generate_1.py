@@ -40,7 +40,8 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
                                         prefill_rows=min(int(vc.get("max_num_batched_tokens", 16384)), 65536) if self.decode_batch > 1 else None)      # (60 000 in the reference config: rows of one packed prefill pass)
         self.mllama_sampling_params = SamplingParams(
             temperature=vc.get("temperature", 0.6), top_p=vc.get("top_p", 0.9), max_tokens=vc.get("max_tokens", 256),
-            min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False))
+            min_tokens=vc.get("min_tokens", 1), ignore_eos=vc.get("ignore_eos", False),
+            stop_token_ids=list(vc["stop_token_ids"]) if vc.get("stop_token_ids") else None)      # (a vllm.SamplingParams field; the reference's config leaves it unset)
         self.mllama_tokenizer, self.mllama_processor = tokenizer, None
         self.visual, self.image_processor, self.image_token_id = None, None, 151655
         self.request_builder = request_builder
@@ -88,27 +89,49 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         chunks = [range(c0, min(c0 + self.decode_batch, n)) for c0 in range(0, n, self.decode_batch)]
         prefetch = len(chunks) > 1 and os.environ.get("TD_PRECOMPUTE_PREFETCH", "1") != "0"
         pool = ThreadPoolExecutor(max_workers=1) if prefetch else None
-        fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[0]) if prefetch else None
+        # TD_PRECOMPUTE_CONTINUOUS=1: continuous batching over the whole loader batch (Qwen2VLTextEngine.generate_continuous -- a finished sequence's
+        # slot goes to a waiting request at once, as in vLLM's scheduler) instead of one generate_batch per chunk of `decode_batch`, which runs every
+        # chunk down to its longest sequence.  Opt-in: with loader batches of 1024 and this model's request builder (0.6-0.9 s per 256 requests on one
+        # helper thread) the scheduler waits for requests more than it saves -- measured 14.0 vs 13.1 s of model time on 2048 samples whose outputs
+        # end at random (mean 110 of 256 tokens), 15.9 vs 15.1 s when every output runs to 256 (profiles/r4as_job_numpy_var_ab.log) -- so the
+        # chunked form stays the default.  The two sample different tokens (the draw of a sequence depends on the step and the row it sits in),
+        # each reproducibly under its seed.
+        continuous = os.environ.get("TD_PRECOMPUTE_CONTINUOUS", "0") == "1"
+        all_reqs, all_outs = [], []
         try:
-            for k, idx in enumerate(chunks):
-                if prefetch:
-                    reqs = fut.result()
-                    fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[k + 1]) if k + 1 < len(chunks) else None
-                else:
-                    reqs = self._requests(mllama_inputs, idx)
-                outs = self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator)
-                for r, o in zip(reqs, outs):
-                    text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
-                    tok["input_prompt"].append(r.get("prompt", ""))
-                    tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
-                    tok["output_text"].append(text)
-                    tok["output_token_ids"].append(tuple(o["token_ids"]))
-                    texts.append(text)
-                    out_embed.append(o["hidden_states"])
-                    in_embed.append(o["prompt_hidden_states"])
+            if continuous:
+                def chunk_source():
+                    fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[0]) if prefetch else None
+                    for k, idx in enumerate(chunks):
+                        reqs = fut.result() if prefetch else self._requests(mllama_inputs, idx)
+                        if prefetch and k + 1 < len(chunks):
+                            fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[k + 1])
+                        all_reqs.extend(reqs)
+                        yield reqs
+                all_outs = self.mllama.generate_continuous(chunk_source(), self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator,
+                                                           max_live=self.decode_batch)
+            else:
+                fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[0]) if prefetch else None
+                for k, idx in enumerate(chunks):
+                    if prefetch:
+                        reqs = fut.result()
+                        fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[k + 1]) if k + 1 < len(chunks) else None
+                    else:
+                        reqs = self._requests(mllama_inputs, idx)
+                    all_reqs.extend(reqs)
+                    all_outs.extend(self.mllama.generate_batch(reqs, self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator))
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)      # (also when a chunk raised: the helper thread does not outlive the call)
+        for r, o in zip(all_reqs, all_outs):
+            text = self.mllama_tokenizer.decode(o["token_ids"]) if self.mllama_tokenizer is not None else " ".join(map(str, o["token_ids"]))
+            tok["input_prompt"].append(r.get("prompt", ""))
+            tok["input_prompt_token_ids"].append(list(r["prompt_token_ids"]))
+            tok["output_text"].append(text)
+            tok["output_token_ids"].append(tuple(o["token_ids"]))
+            texts.append(text)
+            out_embed.append(o["hidden_states"])
+            in_embed.append(o["prompt_hidden_states"])
         return {"generated_text": texts, "generated_token": tok,
                 "generated_embed": {layer: {"output_embed": out_embed, "input_embed": in_embed}}}
 

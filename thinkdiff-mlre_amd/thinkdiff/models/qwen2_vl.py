@@ -146,8 +146,8 @@ class Qwen2VLTextEngine:
                                                  _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
         return hid, lg
 
-    def decode_batch(self, token_ids, position_ids, cache_pos: Sequence[int], want_logits=True):
-        """One token for each of the sequences in slots 0..B-1 in a single pass over the weights.
+    def decode_batch(self, token_ids, position_ids, cache_pos: Sequence[int], want_logits=True, slots: Optional[Sequence[int]] = None):
+        """One token for each of the sequences in cache slots `slots` (default 0..B-1) in a single pass over the weights.
         token_ids [B], position_ids [3,B], cache_pos[b] = tokens already cached.  -> (hidden [B,hidden], logits [B,vocab] | None)."""
         B = len(cache_pos)
         tok = torch.as_tensor(token_ids, dtype=torch.int32).to(self.device).contiguous()
@@ -156,8 +156,9 @@ class Qwen2VLTextEngine:
         hid = torch.empty(B, self.config.hidden_size, dtype=torch.bfloat16, device=self.device)
         lg = torch.empty(B, self.config.vocab_size, dtype=torch.bfloat16, device=self.device) if want_logits else None
         cp = (ctypes.c_int * B)(*[int(c) for c in cache_pos])
-        _hip.check(self._L.td_qwen2_decode_batch(self._h, B, _hip.ptr(tok), _hip.ptr(pos), ctypes.cast(cp, ctypes.c_void_p),
-                                                 _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
+        sl = ctypes.cast((ctypes.c_int * B)(*[int(c) for c in slots]), ctypes.c_void_p) if slots is not None else None
+        _hip.check(self._L.td_qwen2_decode_batch_slots(self._h, B, sl, _hip.ptr(tok), _hip.ptr(pos), ctypes.cast(cp, ctypes.c_void_p),
+                                                       _hip.ptr(hid), _hip.ptr(lg), _hip.stream_ptr()))
         return hid, lg
 
     # ---- multimodal prompt assembly ([ext] vLLM Qwen2-VL input processor + transformers Qwen2VLModel.get_rope_index) ----
@@ -342,7 +343,8 @@ class Qwen2VLTextEngine:
                 res[b]["prompt_hidden_states"] = hid
                 rows.append(lg)
             logits = torch.stack(rows)              # [B, vocab], row i belongs to the sequence in slot i
-        owner = list(range(B))                      # slot -> request index
+        owner = list(range(B))                      # live row -> request index
+        slots = list(range(B))                      # live row -> cache slot (a finished sequence just leaves the lists: no cache rows move)
         key = None if forced_output_ids is not None else self._draw_sampler_key(generator)
         stops = set(sampling.stop_token_ids or [])
         step = 0
@@ -356,7 +358,8 @@ class Qwen2VLTextEngine:
             if forced_output_ids is not None:
                 live = [i for i in range(n) if step < len(forced_output_ids[owner[i]])]
                 if len(live) < n:                   # forced continuations of different lengths: retire the exhausted ones first
-                    self._compact(owner, cache_len, next_pos, live)
+                    owner, slots = [owner[i] for i in live], [slots[i] for i in live]
+                    cache_len, next_pos = [cache_len[i] for i in live], [next_pos[i] for i in live]
                     logits = logits[live]
                     if not owner:
                         break
@@ -366,7 +369,7 @@ class Qwen2VLTextEngine:
                 # one launch for all live rows (td_sample_top_p_bf16); the ids come to the host once per step for the bookkeeping below
                 toks = _OPS.sample_top_p(logits[:n], float(sampling.temperature), float(sampling.top_p), int(key), int(step)).tolist()
             pos = torch.tensor(next_pos[:n], dtype=torch.int32).unsqueeze(0).expand(3, n)
-            hid, logits = self.decode_batch(toks, pos, cache_len[:n])
+            hid, logits = self.decode_batch(toks, pos, cache_len[:n], slots=slots)
             step_hid.append(hid)
             step_owner.append(list(owner))
             step_toks.append(toks)
@@ -379,7 +382,8 @@ class Qwen2VLTextEngine:
                 if not stop and cache_len[i] < self.slot_len:
                     keep.append(i)
             if len(keep) < n:
-                self._compact(owner, cache_len, next_pos, keep)
+                owner, slots = [owner[i] for i in keep], [slots[i] for i in keep]
+                cache_len, next_pos = [cache_len[i] for i in keep], [next_pos[i] for i in keep]
                 logits = logits[keep]
             step += 1
         rows = [[] for _ in range(B)]
@@ -396,6 +400,173 @@ class Qwen2VLTextEngine:
             parts = torch.split(allh.index_select(0, idx), [len(rr) for rr in rows])
         for b, r in enumerate(res):
             r["hidden_states"] = parts[b] if base and rows[b] else torch.empty(0, D, dtype=torch.bfloat16, device=self.device)
+        return res
+
+    @torch.no_grad()
+    def generate_continuous(self, request_chunks, sampling: SamplingParams, eos_token_id: Optional[int] = None,
+                            generator: Optional[torch.Generator] = None, forced_output_ids: Optional[Sequence[Sequence[int]]] = None,
+                            max_live: Optional[int] = None, admit_min: Optional[int] = None):
+        """Continuous batching ([ext] vLLM's scheduler behind the reference's `LLM.generate` of a whole loader batch, thinkdiff/models/
+        mllama_vllm_generate_1.py:585 with `max_num_seqs: 256`): any number of requests against `max_live` (default min(256, n_slots)) cache slots.
+        A sequence that finishes frees its slot at once -- nothing moves: a decode step names the slot of each of its rows
+        (td_qwen2_decode_batch_slots) -- and waiting requests are prefilled into the free slots (one packed pass, td_qwen2_prefill_packed_slots)
+        as soon as `admit_min` of them fit (default max_live / 8: a
+        prefill pass interrupts the decode steps, so it should be worth a pass), then decode with everybody else.  With outputs of different
+        lengths the decode steps stay full, where generate_batch per chunk of max_live runs every chunk down to its longest sequence.
+        `request_chunks`: an iterable of request lists -- pulled only when the waiting queue runs low, so a producer (the precompute model's helper
+        thread) can build later chunks while earlier ones decode -- or one flat list.  Requests are numbered in arrival order; returns one
+        generate()-style dict per request in that order.  forced_output_ids[i]: teacher-forced continuation of request i."""
+        from collections import deque
+        import numpy as np
+        max_live = min(self.MAX_BATCH, getattr(self, "n_slots", 1)) if max_live is None else int(max_live)
+        if max_live < 1 or max_live > min(self.MAX_BATCH, getattr(self, "n_slots", 1)):
+            raise _hip.ThinkDiffHipError(f"generate_continuous: max_live={max_live} exceeds min({self.MAX_BATCH}, n_slots={getattr(self, 'n_slots', 1)}); call set_slots first")
+        admit_min = max(1, max_live // 8) if admit_min is None else max(1, int(admit_min))
+        if isinstance(request_chunks, (list, tuple)) and (not request_chunks or isinstance(request_chunks[0], dict)):
+            request_chunks = [list(request_chunks)]
+        chunk_it = iter(request_chunks)
+        D, V = self.config.hidden_size, self.config.vocab_size
+        requests, res, waiting = [], [], deque()
+        exhausted = False
+
+        def pull():
+            nonlocal exhausted
+            try:
+                chunk = next(chunk_it)
+            except StopIteration:
+                exhausted = True
+                return
+            for r in chunk:
+                n = len(r["prompt_token_ids"])
+                if n < 1 or n > min(self.slot_len, self.prefill_rows):
+                    raise _hip.ThinkDiffHipError(f"generate_continuous: a prompt of {n} tokens does not fit a slot ({self.slot_len}) / a prefill pass ({self.prefill_rows})")
+                waiting.append(len(requests))
+                requests.append(r)
+                res.append({"prompt_hidden_states": None, "hidden_states": None, "token_ids": []})
+
+        # per live row (numpy, rows [0, n)): request, cache slot, cached tokens, next position id, tokens generated, token budget.  The per-step
+        # bookkeeping is vectorised and the arrays are handed to the C ABI as they are: at 256 sequences the Python-list form cost ~2 ms of host
+        # time per step, about as much as the step itself takes on the GPU, and the GPU idles while the host prepares the next launch.
+        own, slt, clen, npos, ngen, lim = (np.zeros(max_live, dtype=np.int32) for _ in range(6))
+        n = 0
+        free_slots = list(range(max_live - 1, -1, -1))      # (a stack: the lowest free slot is taken first)
+        logits = torch.empty(max_live, V, dtype=torch.bfloat16, device=self.device)      # row i = the next-token logits of live row i
+        key = None if forced_output_ids is not None else self._draw_sampler_key(generator)
+        stops = np.array(sorted(set(sampling.stop_token_ids or [])), dtype=np.int64)
+        eos_on = (not sampling.ignore_eos) and eos_token_id is not None
+        can_stop = forced_output_ids is None and (stops.size > 0 or eos_on)
+        step_hid, step_owner, step_toks = [], [], []
+        gstep = 0
+        slot_len, min_tok = self.slot_len, sampling.min_tokens
+        vp = ctypes.c_void_p
+
+        def budget(i):      # tokens request i may still produce
+            return len(forced_output_ids[i]) if forced_output_ids is not None else sampling.max_tokens
+
+        while True:
+            free = max_live - n
+            if not exhausted and not waiting and free > 0:      # lazily: the producer builds the next chunk while the current sequences decode
+                pull()
+            # ---- admission: one packed prefill pass into free slots ----
+            if waiting and free > 0 and (n == 0 or min(free, len(waiting)) >= admit_min or (exhausted and free >= len(waiting))):
+                new, rows = [], 0
+                while waiting and len(new) < free and rows + len(requests[waiting[0]]["prompt_token_ids"]) <= self.prefill_rows:
+                    i = waiting.popleft()
+                    if budget(i) <= 0:      # nothing to generate: the prompt states only, through the first free slot
+                        q = requests[i]
+                        m = len(q["prompt_token_ids"])
+                        e = q.get("inputs_embeds")
+                        res[i]["prompt_hidden_states"], _ = self.forward(
+                            self.text_position_ids(m) if q.get("position_ids") is None else q["position_ids"],
+                            torch.tensor(list(q["prompt_token_ids"]), dtype=torch.int32) if e is None else None, e, 0, True, False, slot=free_slots[-1])
+                        continue
+                    new.append(i)
+                    rows += len(requests[i]["prompt_token_ids"])
+                if new:
+                    k = len(new)
+                    emb = torch.empty(rows, D, dtype=torch.bfloat16, device=self.device)
+                    pos = torch.empty(3, rows, dtype=torch.int32)
+                    lens, r0 = [], 0
+                    for j, i in enumerate(new):
+                        q = requests[i]
+                        m = len(q["prompt_token_ids"])
+                        pp = self.text_position_ids(m) if q.get("position_ids") is None else q["position_ids"]
+                        e = q.get("inputs_embeds")
+                        emb[r0:r0 + m] = self.embed_tokens(q["prompt_token_ids"]) if e is None else e.to(self.device, torch.bfloat16)
+                        pos[:, r0:r0 + m] = pp.to(torch.int32)
+                        lens.append(m)
+                        npos[n + j] = int(pp.max()) + 1
+                        r0 += m
+                    pos = pos.to(self.device).contiguous()
+                    hid = torch.empty(rows, D, dtype=torch.bfloat16, device=self.device)
+                    new_slots = [free_slots.pop() for _ in new]
+                    cl = (ctypes.c_int * k)(*lens)
+                    sl = (ctypes.c_int * k)(*new_slots)
+                    _hip.check(self._L.td_qwen2_prefill_packed_slots(self._h, k, ctypes.cast(sl, vp), None, _hip.ptr(emb), _hip.ptr(pos),
+                                                                     ctypes.cast(cl, vp), _hip.ptr(hid), _hip.ptr(logits[n:n + k]), _hip.stream_ptr()))
+                    r0 = 0
+                    for i, m in zip(new, lens):
+                        res[i]["prompt_hidden_states"] = hid[r0:r0 + m]
+                        r0 += m
+                    own[n:n + k] = new
+                    slt[n:n + k] = new_slots
+                    clen[n:n + k] = lens
+                    ngen[n:n + k] = 0
+                    lim[n:n + k] = [budget(i) for i in new]
+                    n += k
+                    continue      # (more may fit in another pass before the next decode step)
+            if n == 0:
+                if waiting or not exhausted:
+                    continue
+                break
+            # ---- one decode step for every live sequence ----
+            if forced_output_ids is not None:
+                toks = np.array([forced_output_ids[own[i]][ngen[i]] for i in range(n)], dtype=np.int32)
+                tok_dev = torch.from_numpy(toks).to(self.device)
+            else:
+                tok_dev = _OPS.sample_top_p(logits[:n], float(sampling.temperature), float(sampling.top_p), int(key), int(gstep))
+                toks = tok_dev.cpu().numpy()      # (the host sees the ids once per step, for the stop rules below)
+            pos_dev = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(npos[:n], (3, n)))).to(self.device)
+            hid = torch.empty(n, D, dtype=torch.bfloat16, device=self.device)
+            _hip.check(self._L.td_qwen2_decode_batch_slots(self._h, n, vp(slt.ctypes.data), _hip.ptr(tok_dev), _hip.ptr(pos_dev), vp(clen.ctypes.data),
+                                                           _hip.ptr(hid), _hip.ptr(logits), _hip.stream_ptr()))      # logits of row i -> logits[i]
+            step_hid.append(hid)
+            step_owner.append(own[:n].copy())
+            step_toks.append(toks)
+            clen[:n] += 1
+            npos[:n] += 1
+            ngen[:n] += 1
+            done = (ngen[:n] >= lim[:n]) | (clen[:n] >= slot_len)
+            if can_stop:
+                hit = np.isin(toks, stops) if stops.size else np.zeros(n, dtype=bool)
+                if eos_on:
+                    hit |= toks == eos_token_id
+                done |= hit & (ngen[:n] >= min_tok)
+            if done.any():
+                keep = np.nonzero(~done)[0]
+                free_slots.extend(sorted((int(x) for x in slt[:n][done]), reverse=True))
+                k = keep.size
+                for arr in (own, slt, clen, npos, ngen, lim):
+                    arr[:k] = arr[:n][keep]
+                if k:
+                    logits[:k] = logits[:n].index_select(0, torch.from_numpy(keep).to(self.device))
+                n = k
+            gstep += 1
+        N = len(requests)
+        if step_owner:
+            owners_all = np.concatenate(step_owner)
+            order = np.argsort(owners_all, kind="stable")      # rows grouped by request, in step order inside a request
+            counts = np.bincount(owners_all, minlength=N).tolist()
+            parts = torch.split(torch.cat(step_hid).index_select(0, torch.from_numpy(order).to(self.device)), counts)
+            toks_sorted = np.concatenate(step_toks)[order].tolist()
+            r0 = 0
+            for b in range(N):
+                res[b]["hidden_states"] = parts[b]
+                res[b]["token_ids"] = toks_sorted[r0:r0 + counts[b]]
+                r0 += counts[b]
+        else:
+            for r in res:
+                r["hidden_states"] = torch.empty(0, D, dtype=torch.bfloat16, device=self.device)
         return res
 
     def _compact(self, owner, cache_len, next_pos, keep):

@@ -39,6 +39,9 @@ argv = ["--cfg-path", os.path.join(ROOT, "tests", "golden", "qwen2_vl_embed_keys
         "model.vllm_config.max_model_len=2048", f"model.vllm_config.max_tokens={os.environ.get('TD_JOB_TOKENS', '64')}", f"model.vllm_config.min_tokens={os.environ.get('TD_JOB_TOKENS', '64')}", "model.vllm_config.ignore_eos=true",
         f"model.vllm_config.max_num_seqs={os.environ.get('TD_JOB_SEQS', '256')}", f"model.vllm_config.max_num_batched_tokens=60000",
         "model.text_config={hidden_size: 1536, num_hidden_layers: 28, num_attention_heads: 12, num_key_value_heads: 2, intermediate_size: 8960, vocab_size: 151936, tie_word_embeddings: true}"]
+if os.environ.get("TD_JOB_STOP_EVERY"):      # outputs of different lengths (synthetic weights never sample one particular EOS id): every k-th token id ends a sequence
+    k = int(os.environ["TD_JOB_STOP_EVERY"])
+    argv[-1:-1] = ["model.vllm_config.min_tokens=1", "model.vllm_config.stop_token_ids=[" + ",".join(str(i) for i in range(0, 151936, k)) + "]"]
 t = {}
 orig = task_mod.ImageTextProcessDataTask.train_epoch
 def timed(self, *a, **k):
