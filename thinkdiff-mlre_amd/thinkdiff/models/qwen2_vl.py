@@ -465,8 +465,9 @@ class Qwen2VLTextEngine:
 
         while True:
             free = max_live - n
-            if not exhausted and not waiting and free > 0:      # lazily: the producer builds the next chunk while the current sequences decode
+            if not exhausted and len(waiting) < free:      # lazily -- the producer builds the next chunk while the current sequences decode -- but enough to fill the free slots
                 pull()
+                continue
             # ---- admission: one packed prefill pass into free slots ----
             if waiting and free > 0 and (n == 0 or min(free, len(waiting)) >= admit_min or (exhausted and free >= len(waiting))):
                 new, rows = [], 0
@@ -502,8 +503,7 @@ class Qwen2VLTextEngine:
                     new_slots = [free_slots.pop() for _ in new]
                     cl = (ctypes.c_int * k)(*lens)
                     sl = (ctypes.c_int * k)(*new_slots)
-                    _hip.check(self._L.td_qwen2_prefill_packed_slots(self._h, k, ctypes.cast(sl, vp), None, _hip.ptr(emb), _hip.ptr(pos),
-                                                                     ctypes.cast(cl, vp), _hip.ptr(hid), _hip.ptr(logits[n:n + k]), _hip.stream_ptr()))
+                    self._prefill_packed_slots(k, sl, emb, pos, cl, hid, logits[n:n + k])
                     r0 = 0
                     for i, m in zip(new, lens):
                         res[i]["prompt_hidden_states"] = hid[r0:r0 + m]
@@ -528,8 +528,7 @@ class Qwen2VLTextEngine:
                 toks = tok_dev.cpu().numpy()      # (the host sees the ids once per step, for the stop rules below)
             pos_dev = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(npos[:n], (3, n)))).to(self.device)
             hid = torch.empty(n, D, dtype=torch.bfloat16, device=self.device)
-            _hip.check(self._L.td_qwen2_decode_batch_slots(self._h, n, vp(slt.ctypes.data), _hip.ptr(tok_dev), _hip.ptr(pos_dev), vp(clen.ctypes.data),
-                                                           _hip.ptr(hid), _hip.ptr(logits), _hip.stream_ptr()))      # logits of row i -> logits[i]
+            self._decode_slots(n, slt, tok_dev, pos_dev, clen, hid, logits)      # logits of row i -> logits[i]
             step_hid.append(hid)
             step_owner.append(own[:n].copy())
             step_toks.append(toks)
@@ -568,6 +567,15 @@ class Qwen2VLTextEngine:
             for r in res:
                 r["hidden_states"] = torch.empty(0, D, dtype=torch.bfloat16, device=self.device)
         return res
+
+    # the two engine calls of generate_continuous (separate methods so that the scheduler's host logic can be exercised against a stand-in engine)
+    def _prefill_packed_slots(self, k, slots_c, emb, pos, lens_c, hid_out, logits_out):
+        _hip.check(self._L.td_qwen2_prefill_packed_slots(self._h, k, ctypes.cast(slots_c, ctypes.c_void_p), None, _hip.ptr(emb), _hip.ptr(pos),
+                                                         ctypes.cast(lens_c, ctypes.c_void_p), _hip.ptr(hid_out), _hip.ptr(logits_out), _hip.stream_ptr()))
+
+    def _decode_slots(self, n, slots_np, tok_dev, pos_dev, cache_np, hid_out, logits_out):
+        _hip.check(self._L.td_qwen2_decode_batch_slots(self._h, n, ctypes.c_void_p(slots_np.ctypes.data), _hip.ptr(tok_dev), _hip.ptr(pos_dev),
+                                                       ctypes.c_void_p(cache_np.ctypes.data), _hip.ptr(hid_out), _hip.ptr(logits_out), _hip.stream_ptr()))
 
     def _compact(self, owner, cache_len, next_pos, keep):
         """Keep the sequences at slot indices `keep` (ascending) and pack them into slots 0..len(keep)-1."""
