@@ -542,3 +542,35 @@ def test_continuous_batching_equals_one_request_at_a_time(hip):
         for k in range(len(t) - 1):
             assert near_argmax(x["hidden_states"][k], t[k + 1])
     assert len(set(n_tok)) > 2, "the stop tokens end the sequences at different steps (slots are re-used mid-flight)"
+
+
+def test_move_slot_and_slot_indirect_decode_bit_equal(hip):
+    """td_qwen2_move_slot + td_qwen2_decode_batch_slots: a sequence prefilled into slot 5 and moved to slot 1 decodes from there exactly as it does from
+    slot 5 -- alone, and as one row of a step whose rows name scattered slots (6, 1, 3) in an order that is not the slot order."""
+    from thinkdiff.models.qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextEngine
+    cfg = Q.tiny_config()
+    sd = Q.init_weights(cfg, seed=29)
+    tc = Qwen2VLTextConfig(hidden_size=cfg.hidden, num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                           intermediate_size=cfg.intermediate, vocab_size=cfg.vocab, tie_word_embeddings=cfg.tie_embeddings)
+    e = Qwen2VLTextEngine(tc, max_model_len=8 * 96, n_slots=8)
+    e.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    lens = {5: 40, 6: 17, 3: 70}
+    for slot, n in lens.items():
+        e.forward(e.text_position_ids(n), torch.randint(0, cfg.vocab, (n,), generator=g).to(torch.int32), slot=slot)
+    tok = torch.randint(0, cfg.vocab, (3,), generator=g).tolist()
+    pos1 = torch.tensor([[40]] * 3, dtype=torch.int32)
+    h5, l5 = e.decode_batch(tok[:1], pos1, [40], slots=[5])
+    h5, l5 = h5.clone(), l5.clone()
+    e.move_slot(5, 1, 40)                       # (the step above appended a row to slot 5; the first 40 rows are the prompt)
+    h1, l1 = e.decode_batch(tok[:1], pos1, [40], slots=[1])
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h5) and torch.equal(l1, l5)
+    # three rows, scattered slots: row 1 is the moved sequence again (its slot holds 41 rows now; decode the same token at the same place)
+    e.move_slot(5, 1, 40)
+    posb = torch.tensor([[17, 40, 70]] * 3, dtype=torch.int32)
+    hb, lb = e.decode_batch([tok[1], tok[0], tok[2]], posb, [17, 40, 70], slots=[6, 1, 3])
+    torch.cuda.synchronize()
+    assert _rel(hb[1:2], h5) < 2e-3 and torch.isfinite(hb.float()).all()      # (three rows take another Linear kernel than one: not bit-equal, equal to rounding)
+    with pytest.raises(hip.ThinkDiffHipError):
+        e.decode_batch(tok[:2], torch.tensor([[1, 1]] * 3, dtype=torch.int32), [1, 1], slots=[2, 9])      # slot 9 of 8

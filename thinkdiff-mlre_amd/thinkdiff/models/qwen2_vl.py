@@ -577,14 +577,10 @@ class Qwen2VLTextEngine:
         _hip.check(self._L.td_qwen2_decode_batch_slots(self._h, n, ctypes.c_void_p(slots_np.ctypes.data), _hip.ptr(tok_dev), _hip.ptr(pos_dev),
                                                        ctypes.c_void_p(cache_np.ctypes.data), _hip.ptr(hid_out), _hip.ptr(logits_out), _hip.stream_ptr()))
 
-    def _compact(self, owner, cache_len, next_pos, keep):
-        """Keep the sequences at slot indices `keep` (ascending) and pack them into slots 0..len(keep)-1."""
-        for dst, src in enumerate(keep):
-            if dst != src:
-                _hip.check(self._L.td_qwen2_move_slot(self._h, src, dst, cache_len[src], _hip.stream_ptr()))
-        owner[:] = [owner[i] for i in keep]
-        cache_len[:] = [cache_len[i] for i in keep]
-        next_pos[:] = [next_pos[i] for i in keep]
+    def move_slot(self, src: int, dst: int, length: int):
+        """Copy the first `length` cache rows of slot `src` to slot `dst` (td_qwen2_move_slot).  The decode steps name their slots, so nothing in this
+        class needs it any more; it stays for callers that want to defragment a handle before re-partitioning it (set_slots)."""
+        _hip.check(self._L.td_qwen2_move_slot(self._h, int(src), int(dst), int(length), _hip.stream_ptr()))
 
 
 def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 4 * 28 * 28, max_pixels: int = 16384 * 28 * 28):
