@@ -89,14 +89,16 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
         chunks = [range(c0, min(c0 + self.decode_batch, n)) for c0 in range(0, n, self.decode_batch)]
         prefetch = len(chunks) > 1 and os.environ.get("TD_PRECOMPUTE_PREFETCH", "1") != "0"
         pool = ThreadPoolExecutor(max_workers=1) if prefetch else None
-        # TD_PRECOMPUTE_CONTINUOUS=1: continuous batching over the whole loader batch (Qwen2VLTextEngine.generate_continuous -- a finished sequence's
-        # slot goes to a waiting request at once, as in vLLM's scheduler) instead of one generate_batch per chunk of `decode_batch`, which runs every
-        # chunk down to its longest sequence.  Opt-in: with loader batches of 1024 and this model's request builder (0.6-0.9 s per 256 requests on one
-        # helper thread) the scheduler waits for requests more than it saves -- measured 14.0 vs 13.1 s of model time on 2048 samples whose outputs
-        # end at random (mean 110 of 256 tokens), 15.9 vs 15.1 s when every output runs to 256 (profiles/r4as_job_numpy_var_ab.log) -- so the
-        # chunked form stays the default.  The two sample different tokens (the draw of a sequence depends on the step and the row it sits in),
-        # each reproducibly under its seed.
-        continuous = os.environ.get("TD_PRECOMPUTE_CONTINUOUS", "0") == "1"
+        # Continuous batching over the whole loader batch (Qwen2VLTextEngine.generate_continuous -- a finished sequence's slot goes to a waiting request
+        # at once, as in vLLM's scheduler) instead of one generate_batch per chunk of `decode_batch`, which runs every chunk down to its longest
+        # sequence.  Measured on the 2B shape (profiles/r4av_job_continuous_4096.log, r4as_job_numpy_var_ab.log), model seconds per 4096 samples:
+        # outputs that end at random (mean 110 of 256 tokens) 18.2 vs 24.1 with a loader batch of 4096 (16 chunks) -- but 14.0 vs 13.1 per 2048 with
+        # loader batches of 1024 (4 chunks: the scheduler then waits for this model's request builder, 0.6-0.9 s per 256 requests on one helper
+        # thread, more than it saves); outputs that all run to 256 tokens 27.9 vs 26.5.  Default: from 8 chunks per loader batch on (the reference's
+        # loader batch is 8192 = 32 chunks, its outputs end at EOS); TD_PRECOMPUTE_CONTINUOUS=1 / 0 forces either form.  The two sample different
+        # tokens (the draw of a sequence depends on the step and the row it sits in), each reproducibly under its seed.
+        env_c = os.environ.get("TD_PRECOMPUTE_CONTINUOUS", "")
+        continuous = env_c == "1" or (env_c != "0" and len(chunks) >= 8)
         all_reqs, all_outs = [], []
         try:
             if continuous:
