@@ -140,6 +140,26 @@ def test_precompute_job_full_size_qwen2vl_2b_shape(hip, tmp_path):
         # two bf16 paths with different tile shapes / summation orders through 28 layers, each within the engine's 2e-2 of the oracle
         # (tests/test_qwen2_gpu.py, tests/test_flux_full_depth_gpu.py::test_config3...): they may differ from each other by up to the sum
         assert e_i < 4e-2 and e_o < 4e-2, f"sample {k}: batched job vs one-sequence path: prompt {e_i:.4f}, output {e_o:.4f}"
+    # the continuous-batching form of the same job (the default from 8 chunks per loader batch on; forced here): every sample once, the record schema,
+    # one hidden row per generated token, finite -- its sampled tokens differ from the chunked form's by construction (other (step, row) draws)
+    os.environ["TD_PRECOMPUTE_CONTINUOUS"] = "1"
+    try:
+        out_c = tmp_path / "emb_c"
+        task_mod.ImageTextProcessDataTask.train_epoch = timed
+        res_c = job.main(common + [f"run.output_shard_path=[{out_c},'%06d.tar',0]"])
+    finally:
+        os.environ.pop("TD_PRECOMPUTE_CONTINUOUS", None)
+        task_mod.ImageTextProcessDataTask.train_epoch = orig
+    stats_c = res_c[0] if isinstance(res_c, list) else res_c
+    recs_c = sorted((s_ for sh in stats_c["shards"] for s_ in wds_io.read_tar_samples(sh["url"])), key=lambda r: r["__key__"])
+    assert [r["__key__"] for r in recs_c] == [f"sample{k:06d}" for k in range(N_SAMPLES)]
+    for k in (0, 100, 255, 256, N_SAMPLES - 1):
+        jc = recs_c[k][".json"] if isinstance(recs_c[k][".json"], dict) else json.loads(recs_c[k][".json"])
+        ja = recs[k][".json"] if isinstance(recs[k][".json"], dict) else json.loads(recs[k][".json"])
+        oc, ic = _load(recs_c[k][".model.norm.output_embed.pth"]), _load(recs_c[k][".model.norm.input_embed.pth"])
+        assert jc["input_prompt_token_ids"] == ja["input_prompt_token_ids"] and ic.shape == (len(jc["input_prompt_token_ids"]), D)
+        assert oc.shape == (len(jc["output_token_ids"]), D) and 1 <= oc.shape[0] <= max_tokens and torch.isfinite(oc.float()).all()
+        assert torch.equal(ic, _load(recs[k][".model.norm.input_embed.pth"]))          # the prompt states do not depend on the scheduler
     rate = N_SAMPLES / timing["epoch"][0]          # (run a: the shipped form, request prefetch on)
     print(f"[config 4] {N_SAMPLES} samples, Qwen2-VL-2B shape, max_tokens 256: {rate:.1f} samples/s end to end (run a, prefetch on; run b, prefetch off: {timing['epoch']}), "
           f"generated tokens per sample {min(n_out)}..{max(n_out)}; batched vs one-sequence rel-RMSE (prompt, output) {errs}")
