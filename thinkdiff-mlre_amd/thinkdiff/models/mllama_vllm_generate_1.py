@@ -111,7 +111,8 @@ class MllamaVllmGenerate_1(QwenChatFrontend, BaseModel):
                         all_reqs.extend(reqs)
                         yield reqs
                 all_outs = self.mllama.generate_continuous(chunk_source(), self.mllama_sampling_params, eos_token_id=self.eos_token_id, generator=generator,
-                                                           max_live=self.decode_batch)
+                                                           max_live=self.decode_batch,
+                                                           admit_min=int(os.environ["TD_CONTINUOUS_ADMIT_MIN"]) if os.environ.get("TD_CONTINUOUS_ADMIT_MIN") else None)
             else:
                 fut = pool.submit(self._requests_on_side_stream, mllama_inputs, chunks[0]) if prefetch else None
                 for k, idx in enumerate(chunks):
