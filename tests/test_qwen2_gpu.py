@@ -574,3 +574,5 @@ def test_move_slot_and_slot_indirect_decode_bit_equal(hip):
     assert _rel(hb[1:2], h5) < 2e-3 and torch.isfinite(hb.float()).all()      # (three rows take another Linear kernel than one: not bit-equal, equal to rounding)
     with pytest.raises(hip.ThinkDiffHipError):
         e.decode_batch(tok[:2], torch.tensor([[1, 1]] * 3, dtype=torch.int32), [1, 1], slots=[2, 9])      # slot 9 of 8
+    with pytest.raises(hip.ThinkDiffHipError):
+        e.decode_batch(tok[:2], torch.tensor([[17, 17]] * 3, dtype=torch.int32), [17, 17], slots=[6, 6])    # two rows on one slot

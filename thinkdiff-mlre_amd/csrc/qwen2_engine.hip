@@ -13,6 +13,7 @@
 // layer's KV cache rows (dual-output GEMM epilogue), so prefill and decode share one code path:
 // `td_qwen2_forward(tokens at positions [pos0, pos0+n))` attends over cache rows [0, pos0+n).
 // Parameters are addressed by their Hugging Face names (model.layers.N.self_attn.q_proj.weight, ...).
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -547,6 +548,12 @@ int td_qwen2_decode_batch_slots(td_qwen2* f, int B, const int* slots, const int*
   const int D = f->D;
   IntPack ip;
   int max_len = 0;
+  if (slots) {      // two rows on one slot would write the same cache row: refused, not left to corrupt a sequence
+    int sorted[MAX_BATCH];
+    std::copy(slots, slots + B, sorted);
+    std::sort(sorted, sorted + B);
+    TD_CHECK_ARG(std::adjacent_find(sorted, sorted + B) == sorted + B, "td_qwen2_decode_batch: cache slot %d is named by more than one row", *std::adjacent_find(sorted, sorted + B));
+  }
   for (int b = 0; b < B; ++b) {
     const int slot = slots ? slots[b] : b;
     TD_CHECK_ARG(slot >= 0 && slot < f->n_slots, "td_qwen2_decode_batch: sequence %d names cache slot %d of %d", b, slot, f->n_slots);
@@ -703,6 +710,12 @@ int td_qwen2_prefill_packed_slots(td_qwen2* f, int B, const int* slots, const in
   TD_CHECK_ARG(f && slots && position_ids && lens && (token_ids || inputs_embeds), "td_qwen2_prefill_packed: null argument");
   TD_CHECK_ARG(B >= 1 && B <= MAX_BATCH, "td_qwen2_prefill_packed: %d sequences (1 .. %d)", B, MAX_BATCH);
   for (int b = 0; b < B; ++b) TD_CHECK_ARG(slots[b] >= 0 && slots[b] < f->n_slots, "td_qwen2_prefill_packed: sequence %d names cache slot %d of %d", b, slots[b], f->n_slots);
+  {
+    int sorted[MAX_BATCH];
+    std::copy(slots, slots + B, sorted);
+    std::sort(sorted, sorted + B);
+    TD_CHECK_ARG(std::adjacent_find(sorted, sorted + B) == sorted + B, "td_qwen2_prefill_packed: cache slot %d is named by more than one sequence", *std::adjacent_find(sorted, sorted + B));
+  }
   long long total = 0;
   int L = 0;
   for (int b = 0; b < B; ++b) {
